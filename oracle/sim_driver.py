@@ -1,0 +1,206 @@
+"""Simulation loop of the reference's demo driver (test/main.cpp:132-200), backend-agnostic.
+
+TEST INFRASTRUCTURE ONLY.  The ground-truth vehicle, steering controller, sensor model and the
+known-association table run through the CPU oracle (they are harness-side code in the reference too,
+SURVEY.md 2 "OUT OF SCOPE" rows); the filter calls (predict / observeHeading / update / augment) go to
+whatever `backend` is handed in -- the oracle itself, the numpy restatement, or the HIP engine -- so the
+same loop produces the fixture and checks the engine against it.
+
+Noise: the reference draws from a clock-seeded engine on every call (slam.h:587-594, irreproducible,
+SURVEY 2.1 #6); here noise comes from the counter-based generator below, or is switched off.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from pyoracle import Oracle, REF_EXACT
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PI = 3.14159265358979323846264338327950288
+
+
+# ---------------------------------------------------------------------------------------------
+# counter-based RNG shared by every harness: splitmix64(seed, index) -> uniform -> normal
+# ---------------------------------------------------------------------------------------------
+def splitmix64(seed: int, idx) -> np.ndarray:
+    """Vectorised splitmix64 finaliser of (seed * 0x9E3779B97F4A7C15 + idx)."""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.asarray(idx, dtype=np.uint64)
+             + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed: int, idx) -> np.ndarray:
+    """Uniform doubles in [0,1) from the top 53 bits."""
+    return (splitmix64(seed, idx) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def normal(seed: int, idx) -> np.ndarray:
+    """Standard normals by Box-Muller on two independent uniform streams."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    u1 = uniform01(seed, idx * np.uint64(2))
+    u2 = uniform01(seed, idx * np.uint64(2) + np.uint64(1))
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+
+# ---------------------------------------------------------------------------------------------
+class SlamConfig:
+    """Defaults of the reference's public data members, slam.h:65-103."""
+
+    def __init__(self):
+        f = np.float32
+        self.velocity = f(83.33)
+        self.max_swa = f(PI / 4.0)
+        self.rate_swa = f(float(f(70.0)) * PI / 180.0)
+        self.wheel_base = f(73.0)
+        self.dt_controls = 0.01  # double
+        self.sigma_v = f(0.3)
+        self.sigma_swa = f(float(f(1.0)) * PI / 180.0)
+        self.max_range = f(2000.0)
+        self.dt_observe = float(f(5.058)) * self.dt_controls  # double
+        self.sigma_r = f(0.1)
+        self.sigma_b = f(float(f(1.0)) * PI / 180.0)
+        self.gate_reject = f(50.0)
+        self.gate_augment = f(1000.0)
+        self.at_waypoint = f(1.0)
+        self.number_loops = f(1.0)
+        self.num_particles = 100
+        self.num_effective = int(0.75 * self.num_particles)
+        self.switch_control_noise = True
+        self.switch_sensor_noise = True
+        self.switch_inflate_noise = True
+        self.switch_heading_known = True
+        self.switch_association_known = True
+        self.switch_batch_update = True
+        self.switch_sample_proposal = True
+        self.switch_resample = True
+
+
+def load_demo_map(path=None):
+    path = path or os.path.join(_HERE, "..", "tests", "golden", "demo_map.json")
+    d = json.load(open(path))
+    LM = np.array([d["landmarks_x"], d["landmarks_y"]], dtype=np.float32)
+    WP = np.array([d["waypoints_x"], d["waypoints_y"]], dtype=np.float32)
+    return np.asfortranarray(LM), np.asfortranarray(WP)
+
+
+class OracleBackend:
+    """Filter back-end on the C oracle; same surface the HIP engine's Python mirror offers."""
+
+    def __init__(self, dtype=np.float32, quirks=REF_EXACT, max_landmarks=64):
+        self.o = Oracle(dtype, quirks)
+        cap = 3 + 2 * max_landmarks
+        self.X = np.zeros(cap, dtype=dtype)
+        self.P = np.zeros((cap, cap), dtype=dtype, order="F")
+        self.n = 3
+
+    def predict(self, v, swa, Q, wb, dt):
+        self.o.predict(self.X, self.P, self.n, v, swa, Q, wb, dt)
+
+    def observe_heading(self, phi, use):
+        self.o.observe_heading(self.X, self.P, self.n, phi, use)
+
+    def update(self, Z, R, idf, batch):
+        return self.o.update(self.X, self.P, self.n, Z, R, idf, batch)
+
+    def augment(self, Z, R):
+        self.n = self.o.augment(self.X, self.P, self.n, Z, R)
+
+    def get_x(self):
+        return self.X[: self.n].copy()
+
+    def get_p(self):
+        return np.array(self.P[: self.n, : self.n], order="F")
+
+
+def run_demo(backend, LM, WP, cfg: SlamConfig = None, noise_seed=None, max_steps=None, dtype=np.float32,
+             record_every=0, int_signum=True):
+    """The EKF loop of test/main.cpp:89-200.  Returns a summary dict.
+
+    noise_seed=None -> control and sensor noise switched off; otherwise seeded counter-based noise.
+    int_signum: True reproduces slam.h:317/324's signum<int>() truncation (the steering only moves while
+    the heading error exceeds 1 rad); False is the plain sign (the variant SURVEY.md's probe numbers used).
+    """
+    cfg = cfg or SlamConfig()
+    sim = Oracle(dtype)  # harness-side helpers at the reference's precision
+    f = np.dtype(dtype).type
+    Q = np.array([[cfg.sigma_v * cfg.sigma_v, 0], [0, cfg.sigma_swa * cfg.sigma_swa]], dtype=dtype, order="F")
+    R = np.array([[cfg.sigma_r * cfg.sigma_r, 0], [0, cfg.sigma_b * cfg.sigma_b]], dtype=dtype, order="F")
+    QE, RE = Q.copy(order="F"), R.copy(order="F")
+    if cfg.switch_inflate_noise:
+        QE, RE = (2 * Q).astype(dtype, order="F"), (8 * R).astype(dtype, order="F")  # main.cpp:125-129
+    XTrue = np.zeros(3, dtype=dtype)
+    dt = cfg.dt_controls
+    dtf = f(dt)
+    dtsum = 0.0
+    nlm = LM.shape[1]
+    table = np.zeros(nlm, dtype=np.int32)
+    iwp, swa = 1, f(0.0)
+    loops = float(cfg.number_loops)
+    LMd, WPd = LM.astype(dtype, order="F"), WP.astype(dtype, order="F")
+    steps = n_obs_events = n_updates = max_m = sum_m = 0
+    wp_switch_steps = []
+    noisy = noise_seed is not None
+    trace = []
+    while 0 < iwp <= WP.shape[1]:
+        steps += 1
+        prev = iwp
+        iwp, swa = sim.compute_swa(XTrue, WPd, iwp, cfg.at_waypoint, swa, cfg.rate_swa, cfg.max_swa, dtf, int_signum)
+        if iwp != prev:
+            wp_switch_steps.append(steps)
+        if iwp == 0 and loops > 1:
+            iwp = 1
+            loops -= 1
+        sim.vehicle_model(XTrue, cfg.velocity, swa, cfg.wheel_base, dtf)
+        vn, swan = cfg.velocity, swa
+        if noisy and cfg.switch_control_noise:  # slam.h:149-159
+            vn = f(vn + f(normal(noise_seed, 2 * steps)) * f(np.sqrt(Q[0, 0])))
+            swan = f(swan + f(normal(noise_seed, 2 * steps + 1)) * f(np.sqrt(Q[1, 1])))
+        backend.predict(vn, swan, QE, cfg.wheel_base, dtf)
+        backend.observe_heading(XTrue[2], cfg.switch_heading_known)
+        dtsum += dt
+        if dtsum >= cfg.dt_observe:
+            dtsum = 0.0
+            Z, tags = sim.get_observations(XTrue, LMd, cfg.max_range)
+            if noisy and cfg.switch_sensor_noise and Z.shape[1] > 0:  # slam.h:168-178
+                base = (10_000_000 + steps) * 64
+                for c in range(Z.shape[1]):
+                    Z[0, c] = f(Z[0, c] + f(normal(noise_seed + 1, base + 2 * c)) * f(np.sqrt(R[0, 0])))
+                    Z[1, c] = f(Z[1, c] + f(normal(noise_seed + 1, base + 2 * c + 1)) * f(np.sqrt(R[1, 1])))
+            if Z.size > 0:
+                n_obs_events += 1
+                nf = (backend.n - 3) // 2
+                ZF, ZN, idf = sim.data_associate_table(Z, tags, table, nf)
+                if ZF.shape[1] > 0:
+                    n_updates += 1
+                    max_m = max(max_m, ZF.shape[1])
+                    sum_m += ZF.shape[1]
+                backend.update(ZF, RE, idf, cfg.switch_batch_update)
+                backend.augment(ZN, RE)
+        if record_every and steps % record_every == 0:
+            trace.append(backend.get_x()[:3].copy())
+        if max_steps is not None and steps >= max_steps:
+            break
+    X = backend.get_x()
+    P = backend.get_p()
+    return {
+        "steps": steps,
+        "obs_events": n_obs_events,
+        "updates": n_updates,
+        "max_m": max_m,
+        "mean_m": (sum_m / n_updates) if n_updates else 0.0,
+        "final_n": int(backend.n),
+        "trace_P": float(np.trace(P.astype(np.float64))),
+        "X_pose": [float(v) for v in X[:3]],
+        "XTrue": [float(v) for v in XTrue],
+        "wp_switch_steps": wp_switch_steps,
+        "X": X,
+        "P": P,
+        "pose_trace": np.array(trace) if trace else None,
+    }
