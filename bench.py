@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- EKF update steps/sec on the MI355X engine (BASELINE.json metric), one JSON line.
+
+Workload at N = 1 (default): BASELINE.json configs[2], the configuration the north-star quotes its
+target on -- EKF-SLAM, 5 000 synthetic landmarks (n = 10 003, P = 400 MB), fp32, one MI355X, m = 32
+observations per batch update (k = 64).  A "step" is one predict() + one batch update() of the filter
+(EKF.cpp:406-455, 481-496) on synthetic inputs (conan_slam_amd/synth.py) that are already
+resident in HBM when the timed region starts; nothing returns to the host inside the timed region.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): a single EKF does not shard (one dense
+P, DESIGN.md "replicas only"), so every rank runs an independent filter instance of the same size with
+its own seed (the Monte-Carlo arrangement of BASELINE configs[4]); no data-path collective; the value
+is (sum of steps over ranks) / (max time over ranks); scaling = weak.
+
+The JSON line also carries
+  roofline      the downdate kernel (P -= W1 W1^T, slam.h:260), timed live with HIP events on the engine's
+                stream around every launch of the timed region;
+  cpu_baseline  the CPU oracle's dense-order port of the same update (oracle/slam_oracle_fast.c), timed on
+                this host on a bounded sample, rank 0 / N = 1 only.  Reported, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TF = {"f32": 157.3, "f64": 78.6}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--landmarks", type=int, default=5000)
+    ap.add_argument("--obs", type=int, default=32, help="observations per batch update (k = 2*obs)")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--quirks", choices=["textbook", "ref_exact"], default="textbook",
+                    help="gain algebra; identical cost. REF_EXACT on this synthetic map turns every update after the "
+                         "first into the reference's LLT-failure no-op (DESIGN.md), so the timed loop uses TEXTBOOK")
+    ap.add_argument("--sequential", action="store_true", help="batch=false (EKF.cpp:457-479)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-profile", action="store_true", help="extra untimed pass with events around every stage")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, dtype):
+    """Times the oracle's dense-order port on the SAME workload on this host (1 core)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pyoracle import Oracle, REF_EXACT, TEXTBOOK  # cpu_baseline leg only
+
+    from conan_slam_amd.synth import Workload
+
+    w = Workload(args.landmarks, args.obs, dtype, seed=0)
+    o = Oracle(dtype, TEXTBOOK if args.quirks == "textbook" else REF_EXACT)
+    X, P = w.X0.copy(), w.P0.copy(order="F")
+    done, t_total = 0, 0.0
+    while done < 2 or (t_total < args.cpu_baseline_seconds and done < 50):
+        v, swa = w.controls(done)
+        Z, idf = w.observations(done)
+        t0 = time.perf_counter()
+        o.predict(X, P, w.n, v, swa, w.QE, w.wb, w.dt)
+        o.update(X, P, w.n, Z, w.RE, idf, True, fast=True)
+        dt = time.perf_counter() - t0
+        if done > 0 or args.cpu_baseline_seconds <= 0:  # the first call pays first-touch of the temporaries
+            t_total += dt
+        done += 1
+        if done >= 2 and t_total >= args.cpu_baseline_seconds:
+            break
+    timed = max(done - 1, 1)
+    return {
+        "value": timed / t_total if t_total > 0 else None,
+        "unit": "update steps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{timed} predict+batch-update steps (after 1 untimed) of the same workload: n={w.n}, m={args.obs}, "
+                  f"{args.dtype}, dense operation order of slam.h:235-266 (oracle/slam_oracle_fast.c, gcc -O3 AVX2)",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dtype = np.float32 if args.dtype == "f32" else np.float64
+    esize = np.dtype(dtype).itemsize
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import conan_slam_amd
+    from conan_slam_amd import EKF, Q_REF_EXACT, Q_TEXTBOOK
+    from conan_slam_amd.synth import Workload
+
+    if conan_slam_amd.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+
+    total_steps = args.warmup + args.steps
+    w = Workload(args.landmarks, args.obs, dtype, seed=rank)
+    n, m, k = w.n, args.obs, 2 * args.obs
+    quirks = Q_TEXTBOOK if args.quirks == "textbook" else Q_REF_EXACT
+    eng = EKF(args.landmarks, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
+    eng.set_state(w.X0, w.P0)
+    w.P0 = None  # free 400 MB of host memory
+
+    # inputs of every step, generated up front and made resident in HBM
+    ctrl = []
+    Zall = np.zeros((total_steps, 2 * m), dtype=dtype)
+    Iall = np.zeros((total_steps, m), dtype=np.int32)
+    for t in range(total_steps):
+        ctrl.append(w.controls(t))
+        Z, idf = w.observations(t)
+        Zall[t] = Z.reshape(-1, order="F")
+        Iall[t] = idf
+    dZ = torch.from_numpy(Zall).cuda()
+    dI = torch.from_numpy(Iall).cuda()
+    torch.cuda.synchronize()
+    zp, ip = dZ.data_ptr(), dI.data_ptr()
+    batch = not args.sequential
+
+    def step(t):
+        v, swa = ctrl[t]
+        eng.predict(v, swa, w.QE, w.wb, w.dt)
+        eng.update_device(zp + t * 2 * m * esize, m, w.RE, ip + t * m * 4, batch=batch)
+
+    def barrier():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for t in range(args.warmup):
+        step(t)
+    barrier()
+    eng.set_profiling(2)  # HIP events around every downdate launch of the timed region, on the engine's stream
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total_steps):
+        step(t)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    stages = eng.stage_times()
+    eng.set_profiling(0)
+    flags = eng.factor_status()
+    trace_end = eng.trace()
+
+    stage_profile = None
+    if args.stage_profile and rank == 0:
+        eng.set_profiling(1)
+        for t in range(args.warmup, min(total_steps, args.warmup + 50)):
+            step(t)
+        st = eng.stage_times()
+        eng.set_profiling(0)
+        stage_profile = {name: (ms / max(cnt, 1)) * 1e3 for name, (ms, cnt) in st.items()}  # us per launch
+
+    if rank != 0:
+        eng.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    dd_ms, dd_cnt = stages["downdate"]
+    dd_s = (dd_ms / max(dd_cnt, 1)) * 1e-3
+    # algorithmic bytes of one downdate launch: P read once + written once, W1 read once
+    dd_bytes = 2.0 * n * n * esize + 1.0 * n * k * esize
+    dd_flops = 2.0 * n * n * k
+    achieved = dd_bytes / dd_s / 1e9 if dd_s > 0 else None
+    out = {
+        "metric": "ekf_update_steps_per_sec",
+        "value": world * args.steps / elapsed,
+        "unit": "update steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"EKF-SLAM predict+{'batch' if batch else 'sequential'} update, {args.landmarks} synthetic landmarks "
+                        f"(n={n}), m={m} observations/step (k={k}), {args.dtype}, one independent filter per GPU",
+            "landmarks": args.landmarks,
+            "n": n,
+            "obs_per_update": m,
+            "k": k,
+            "gain_algebra": args.quirks,
+            "parallelism": f"replicas x{world} (no collective)",
+            "baseline_config": "BASELINE.json configs[2]" if (args.landmarks, args.dtype) == (5000, "f32") else "custom",
+        },
+        "roofline": {
+            "kernel": "ekf_downdate_" + args.dtype,
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": dd_bytes,
+            "launch_us": dd_s * 1e6,
+            "launches_timed": dd_cnt,
+            "mfma_tflops_issued": dd_flops / dd_s / 1e12 if dd_s > 0 else None,
+            "mfma_frac_of_peak": (dd_flops / dd_s / 1e12 / MFMA_PEAK_TF[args.dtype]) if dd_s > 0 else None,
+        },
+        "factor_flags": flags,
+        "trace_P_end": trace_end,
+    }
+    if stage_profile:
+        out["stage_us"] = stage_profile
+    if world == 1 and not args.no_cpu_baseline:
+        eng.close()
+        out["cpu_baseline"] = cpu_baseline(args, dtype)
+        if out["cpu_baseline"]["value"]:
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    else:
+        eng.close()
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

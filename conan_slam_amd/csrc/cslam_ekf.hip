@@ -1,0 +1,954 @@
+// cslam_ekf.hip -- host side of the EKF-SLAM engine behind the C ABI of include/cslam.h.
+//
+// One handle = one filter instance bound to one device and one HIP stream; X and P live in HBM for the
+// lifetime of the handle.  update() is a chain of four launches (gather, factor, gain, downdate) on the
+// handle's stream; nothing returns to the host unless the caller asks (get_x / get_state / sync mode).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <new>
+#include <vector>
+
+#include "cslam_common.hpp"
+#include "ekf_kernels.hpp"
+#include "host_linalg.hpp"
+
+using namespace cslam;
+
+namespace
+{
+
+constexpr int    kStagingSlots = 64;
+constexpr size_t kLdsBudget    = 150 * 1024; // of the 160 KiB per CU, leave room for the small arrays
+
+struct EkfBase
+{
+    virtual ~EkfBase() {}
+    int         dtype    = CSLAM_F32;
+    int         device   = 0;
+    int         quirks   = CSLAM_Q_REF_EXACT;
+    int         nmax     = 0; // max landmarks
+    int         ncap     = 0; // 3 + 2*nmax
+    int         ldp      = 0; // padded leading dimension / column count
+    int         n        = 3;
+    int         sync_mode = 1;
+    hipStream_t stream   = nullptr;
+
+    virtual int init()                                                                        = 0;
+    virtual int set_state(const void* X, int n, const void* P, int ldp)                        = 0;
+    virtual int get_state(void* X, void* P, int ldp)                                           = 0;
+    virtual int get_x(void* X, int cap)                                                        = 0;
+    virtual int trace(double* tr)                                                              = 0;
+    virtual int predict(double v, double swa, const void* Q, double wb, double dt)             = 0;
+    virtual int update(const void* Z, int m, const void* R, const int* idf, int batch, bool on_device) = 0;
+    virtual int augment(const void* Z, int q, const void* R)                                   = 0;
+    virtual int observe_heading(double phi, int use)                                           = 0;
+    virtual int factor_status(int* flags, int clear)                                           = 0;
+    virtual int set_profiling(int on)                                                          = 0;
+    virtual int get_stage_times(double* ms, int* launches)                                     = 0;
+    virtual int debug_last_update(void* PHT, void* S, void* G, void* W1, void* V, int* k)      = 0;
+};
+
+template <typename T>
+struct Ekf : EkfBase
+{
+    T*   dX = nullptr;
+    T*   dP = nullptr;
+    // update workspace
+    int  kcap  = 0;
+    T*   dPHT  = nullptr;
+    T*   dW1   = nullptr;
+    T*   dS    = nullptr;
+    T*   dG    = nullptr;
+    T*   dGt   = nullptr;
+    T*   dV    = nullptr;
+    T*   dt_   = nullptr;
+    T*   dScrS = nullptr;
+    T*   dScrG = nullptr;
+    int* dFlags = nullptr; // [0] sticky, [1] last
+    int* hFlags = nullptr; // pinned mirror
+    // heading scratch: w, cp2, rrow (ldp each) + 2 scalars
+    T* dHead = nullptr;
+    // observation staging: pinned host ring + one device buffer
+    int         mcap   = 0;
+    void*       hStage = nullptr;
+    void*       dStage = nullptr;
+    hipEvent_t  stage_ev[kStagingSlots];
+    bool        stage_ev_used[kStagingSlots];
+    int         stage_next = 0;
+    // status
+    int sticky_host = 0; // flags raised by host-side decisions (FALLBACK/SKIPPED)
+    int last_k      = 0;
+    // profiling
+    int                     profiling = 0;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int>        ev_stage; // stage id of interval [2i, 2i+1]
+    size_t                  ev_used = 0;
+
+    ~Ekf() override
+    {
+        if (stream)
+        {
+            (void)hipStreamSynchronize(stream);
+        }
+        for (hipEvent_t e : ev_pool)
+        {
+            (void)hipEventDestroy(e);
+        }
+        for (int i = 0; i < kStagingSlots; i++)
+        {
+            if (stage_ev_used[i])
+            {
+                (void)hipEventDestroy(stage_ev[i]);
+            }
+        }
+        (void)hipFree(dX);
+        (void)hipFree(dP);
+        free_workspace();
+        (void)hipFree(dFlags);
+        (void)hipFree(dHead);
+        (void)hipFree(dStage);
+        if (hStage)
+        {
+            (void)hipHostFree(hStage);
+        }
+        if (hFlags)
+        {
+            (void)hipHostFree(hFlags);
+        }
+        if (stream)
+        {
+            (void)hipStreamDestroy(stream);
+        }
+    }
+
+    void free_workspace()
+    {
+        (void)hipFree(dPHT);
+        (void)hipFree(dW1);
+        (void)hipFree(dS);
+        (void)hipFree(dG);
+        (void)hipFree(dGt);
+        (void)hipFree(dV);
+        (void)hipFree(dt_);
+        (void)hipFree(dScrS);
+        (void)hipFree(dScrG);
+        dPHT = dW1 = dS = dG = dGt = dV = dt_ = dScrS = dScrG = nullptr;
+    }
+
+    int use_device() { CSLAM_HIP_TRY(hipSetDevice(device)); return CSLAM_OK; }
+
+    int init() override
+    {
+        for (int i = 0; i < kStagingSlots; i++)
+        {
+            stage_ev_used[i] = false;
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        size_t pbytes = (size_t)ldp * ldp * sizeof(T);
+        CSLAM_HIP_TRY(hipMalloc(&dX, (size_t)ldp * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dP, pbytes));
+        CSLAM_HIP_TRY(hipMemsetAsync(dX, 0, (size_t)ldp * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dP, 0, pbytes, stream));
+        CSLAM_HIP_TRY(hipMalloc(&dFlags, 2 * sizeof(int)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dFlags, 0, 2 * sizeof(int), stream));
+        CSLAM_HIP_TRY(hipHostMalloc(&hFlags, 2 * sizeof(int), hipHostMallocDefault));
+        CSLAM_HIP_TRY(hipMalloc(&dHead, ((size_t)3 * ldp + 2) * sizeof(T)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dHead, 0, ((size_t)3 * ldp + 2) * sizeof(T), stream));
+        // allow the factor kernel its large dynamic LDS
+        CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_kernel<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        rc = ensure_k(64);
+        if (rc)
+        {
+            return rc;
+        }
+        rc = ensure_m(64);
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    // workspace for batches of up to k rows of H
+    int ensure_k(int k)
+    {
+        if (k <= kcap)
+        {
+            return CSLAM_OK;
+        }
+        int newk = std::max(k, 2 * kcap);
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        free_workspace();
+        size_t pan = (size_t)ldp * newk * sizeof(T);
+        size_t kk  = (size_t)newk * (newk + 1) * sizeof(T);
+        CSLAM_HIP_TRY(hipMalloc(&dPHT, pan));
+        CSLAM_HIP_TRY(hipMalloc(&dW1, pan));
+        CSLAM_HIP_TRY(hipMalloc(&dS, kk));
+        CSLAM_HIP_TRY(hipMalloc(&dG, kk));
+        CSLAM_HIP_TRY(hipMalloc(&dGt, kk));
+        CSLAM_HIP_TRY(hipMalloc(&dScrS, kk));
+        CSLAM_HIP_TRY(hipMalloc(&dScrG, kk));
+        CSLAM_HIP_TRY(hipMalloc(&dV, (size_t)newk * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dt_, (size_t)newk * sizeof(T)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPHT, 0, pan, stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, pan, stream));
+        kcap = newk;
+        return CSLAM_OK;
+    }
+
+    size_t slot_bytes(int mc) const { return (size_t)mc * (2 * sizeof(T) + sizeof(int)); }
+
+    int ensure_m(int m)
+    {
+        if (m <= mcap)
+        {
+            return CSLAM_OK;
+        }
+        int newm = std::max(m, 2 * mcap);
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        if (hStage)
+        {
+            (void)hipHostFree(hStage);
+            hStage = nullptr;
+        }
+        (void)hipFree(dStage);
+        dStage = nullptr;
+        CSLAM_HIP_TRY(hipHostMalloc(&hStage, slot_bytes(newm) * kStagingSlots, hipHostMallocDefault));
+        CSLAM_HIP_TRY(hipMalloc(&dStage, slot_bytes(newm)));
+        mcap = newm;
+        return CSLAM_OK;
+    }
+
+    // copies (Z, idf) of one call into a pinned slot and enqueues the H2D copy; returns device pointers
+    int stage_obs(const void* Z, const int* idf, int m, const T** dZ, const int** dIdf)
+    {
+        int rc = ensure_m(m);
+        if (rc)
+        {
+            return rc;
+        }
+        int slot = stage_next;
+        stage_next = (stage_next + 1) % kStagingSlots;
+        if (stage_ev_used[slot])
+        {
+            CSLAM_HIP_TRY(hipEventSynchronize(stage_ev[slot]));
+        }
+        else
+        {
+            CSLAM_HIP_TRY(hipEventCreateWithFlags(&stage_ev[slot], hipEventDisableTiming));
+            stage_ev_used[slot] = true;
+        }
+        unsigned char* hs = static_cast<unsigned char*>(hStage) + slot_bytes(mcap) * slot;
+        size_t         zb = (size_t)m * 2 * sizeof(T);
+        memcpy(hs, Z, zb);
+        memcpy(hs + zb, idf, (size_t)m * sizeof(int));
+        CSLAM_HIP_TRY(hipMemcpyAsync(dStage, hs, zb + (size_t)m * sizeof(int), hipMemcpyHostToDevice, stream));
+        CSLAM_HIP_TRY(hipEventRecord(stage_ev[slot], stream));
+        *dZ   = static_cast<const T*>(dStage);
+        *dIdf = reinterpret_cast<const int*>(static_cast<unsigned char*>(dStage) + zb);
+        return CSLAM_OK;
+    }
+
+    // ---------------------------------------------------------------- state transfer
+    int set_state(const void* X, int nn, const void* P, int ldph) override
+    {
+        if (!X || !P || nn < 3 || nn > ncap || ((nn - 3) & 1) || ldph < nn)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "set_state: bad n=%d (cap %d) or ldp=%d", nn, ncap, ldph);
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(dX, X, (size_t)nn * sizeof(T), hipMemcpyHostToDevice, stream));
+        CSLAM_HIP_TRY(hipMemcpy2DAsync(dP, (size_t)ldp * sizeof(T), P, (size_t)ldph * sizeof(T), (size_t)nn * sizeof(T),
+                                       (size_t)nn, hipMemcpyHostToDevice, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        n = nn;
+        return CSLAM_OK;
+    }
+
+    int get_state(void* X, void* P, int ldph) override
+    {
+        if (ldph < n && P)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "get_state: ldp=%d < n=%d", ldph, n);
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        if (X)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(X, dX, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        }
+        if (P)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(P, (size_t)ldph * sizeof(T), dP, (size_t)ldp * sizeof(T),
+                                           (size_t)n * sizeof(T), (size_t)n, hipMemcpyDeviceToHost, stream));
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    int get_x(void* X, int cap) override
+    {
+        if (!X || cap < n)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "get_x: capacity %d < n=%d", cap, n);
+        }
+        return get_state(X, nullptr, 0);
+    }
+
+    int trace(double* tr) override
+    {
+        if (!tr)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "trace: null");
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        std::vector<T> diag((size_t)n);
+        CSLAM_HIP_TRY(hipMemcpy2DAsync(diag.data(), sizeof(T), dP, ((size_t)ldp + 1) * sizeof(T), sizeof(T), (size_t)n,
+                                       hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        double s = 0.0;
+        for (T d : diag)
+        {
+            s += (double)d;
+        }
+        *tr = s;
+        return CSLAM_OK;
+    }
+
+    // ---------------------------------------------------------------- profiling
+    int prof_begin(int stage)
+    {
+        if (!profiling || (profiling == 2 && stage != CSLAM_STAGE_DOWNDATE))
+        {
+            return CSLAM_OK;
+        }
+        if (ev_used + 2 > ev_pool.size())
+        {
+            for (int i = 0; i < 2; i++)
+            {
+                hipEvent_t e;
+                CSLAM_HIP_TRY(hipEventCreate(&e));
+                ev_pool.push_back(e);
+            }
+        }
+        ev_stage.resize(ev_pool.size() / 2);
+        ev_stage[ev_used / 2] = stage;
+        CSLAM_HIP_TRY(hipEventRecord(ev_pool[ev_used], stream));
+        return CSLAM_OK;
+    }
+    int prof_end(int stage)
+    {
+        if (!profiling || (profiling == 2 && stage != CSLAM_STAGE_DOWNDATE))
+        {
+            return CSLAM_OK;
+        }
+        CSLAM_HIP_TRY(hipEventRecord(ev_pool[ev_used + 1], stream));
+        ev_used += 2;
+        return CSLAM_OK;
+    }
+    int set_profiling(int on) override
+    {
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        profiling = on;
+        ev_used   = 0;
+        return CSLAM_OK;
+    }
+    int get_stage_times(double* ms, int* launches) override
+    {
+        if (!ms || !launches)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "get_stage_times: null");
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        for (int s = 0; s < CSLAM_N_STAGES; s++)
+        {
+            ms[s]       = 0.0;
+            launches[s] = 0;
+        }
+        for (size_t i = 0; i + 1 < ev_used; i += 2)
+        {
+            float t = 0.f;
+            CSLAM_HIP_TRY(hipEventElapsedTime(&t, ev_pool[i], ev_pool[i + 1]));
+            int s = ev_stage[i / 2];
+            ms[s] += (double)t;
+            launches[s] += 1;
+        }
+        return CSLAM_OK;
+    }
+
+    // ---------------------------------------------------------------- predict (EKF.cpp:406-455)
+    int predict(double v, double swa, const void* Qv, double wb, double dt) override
+    {
+        if (!Qv)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "predict: Q is null");
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const T* Q = static_cast<const T*>(Qv);
+        int      w = 0;
+        if (n > 3)
+        {
+            w = (quirks & CSLAM_Q_PREDICT_NM4) ? (n - 4) : (n - 3);
+        }
+        hipLaunchKernelGGL(ekf_predict_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, (T)v, (T)swa, Q[0],
+                           Q[1], Q[2], Q[3], (T)wb, (T)dt, w);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    // ---------------------------------------------------------------- update
+    int launch_factor(const T* dZ, const int* dIdf, int m, const T* R)
+    {
+        const int     k = 2 * m;
+        FactorArgs<T> a;
+        a.X   = dX;
+        a.n   = n;
+        a.Z   = dZ;
+        a.idf = dIdf;
+        a.m   = m;
+        for (int i = 0; i < 4; i++)
+        {
+            a.R[i] = R[i];
+        }
+        a.PHT      = dPHT;
+        a.ldw      = ldp;
+        a.dS       = dS;
+        a.dG       = dG;
+        a.dGt      = dGt;
+        a.dV       = dV;
+        a.dt       = dt_;
+        a.flags    = dFlags;
+        a.scratchS = dScrS;
+        a.scratchG = dScrG;
+        a.textbook = (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1;
+        size_t mat   = (size_t)k * (k + 1) * sizeof(T);
+        size_t small = ((size_t)m * 10 + k) * sizeof(T) + ((size_t)m + 4) * sizeof(int) + 64;
+        a.lds_S      = (mat + small <= kLdsBudget) ? 1 : 0;
+        a.lds_G      = (a.lds_S && 2 * mat + small <= kLdsBudget) ? 1 : 0;
+        size_t lds   = small + (a.lds_S ? mat : 0) + (a.lds_G ? mat : 0);
+        hipLaunchKernelGGL(ekf_factor_kernel<T>, dim3(1), dim3(kFactorThreads), lds, stream, a);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    int launch_gain(int k)
+    {
+        const int n_pad = round_up(n, kTile);
+        hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
+                           dW1, dX);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    int launch_downdate(int k);
+
+    // one batch of m observations with device-resident Z / idf (slam.h:235-266 via EKF.cpp:93-129)
+    int batch_on_device(const T* dZ, const int* dIdf, int m, const T* R)
+    {
+        const int k  = 2 * m;
+        int       rc = ensure_k(k);
+        if (rc)
+        {
+            return rc;
+        }
+        last_k = k;
+        if ((rc = prof_begin(CSLAM_STAGE_GATHER)))
+        {
+            return rc;
+        }
+        hipLaunchKernelGGL(ekf_gather_kernel<T>, dim3((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs), dim3(256), 0,
+                           stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp);
+        CSLAM_HIP_TRY(hipGetLastError());
+        if ((rc = prof_end(CSLAM_STAGE_GATHER)) || (rc = prof_begin(CSLAM_STAGE_FACTOR)) ||
+            (rc = launch_factor(dZ, dIdf, m, R)) || (rc = prof_end(CSLAM_STAGE_FACTOR)) ||
+            (rc = prof_begin(CSLAM_STAGE_GAIN)) || (rc = launch_gain(k)) || (rc = prof_end(CSLAM_STAGE_GAIN)) ||
+            (rc = prof_begin(CSLAM_STAGE_DOWNDATE)) || (rc = launch_downdate(k)) ||
+            (rc = prof_end(CSLAM_STAGE_DOWNDATE)))
+        {
+            return rc;
+        }
+        if (sync_mode)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(hFlags, dFlags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            if (hFlags[1] & kFlagLltFailed)
+            {
+                return eigen_fallback(k);
+            }
+        }
+        return CSLAM_OK;
+    }
+
+    // slam.h:425-429 on the host: the device left X and P untouched (G = 0, t = 0)
+    int eigen_fallback(int k)
+    {
+        sticky_host |= CSLAM_FACTOR_FALLBACK;
+        std::vector<T> S((size_t)k * k), V((size_t)k), G;
+        CSLAM_HIP_TRY(hipMemcpyAsync(S.data(), dS, S.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipMemcpyAsync(V.data(), dV, V.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        bool textbook = !(quirks & CSLAM_Q_LOWER_CHOL_GAIN);
+        if (!host_eigen_fallback_gain(S.data(), k, textbook, G))
+        {
+            sticky_host |= CSLAM_FACTOR_ZEROED;
+            return CSLAM_OK; // zeros: the update is a no-op, which is what the device already did
+        }
+        std::vector<T> Gt((size_t)k * k), t((size_t)k, (T)0);
+        for (int c = 0; c < k; c++)
+        {
+            for (int r = 0; r < k; r++)
+            {
+                Gt[(size_t)r * k + c] = G[(size_t)c * k + r];
+                t[c] += G[(size_t)c * k + r] * V[r];
+            }
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(dG, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        CSLAM_HIP_TRY(hipMemcpyAsync(dGt, Gt.data(), Gt.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        CSLAM_HIP_TRY(hipMemcpyAsync(dt_, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        int rc;
+        if ((rc = launch_gain(k)) || (rc = launch_downdate(k)))
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    int update(const void* Zv, int m, const void* Rv, const int* idf, int batch, bool on_device) override
+    {
+        if (m < 0 || !Rv || (m > 0 && (!Zv || !idf)))
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "update: bad arguments (m=%d)", m);
+        }
+        if (m == 0)
+        {
+            return CSLAM_OK; // EKF.cpp:101-123 with an empty Z: nothing changes
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const T*   R    = static_cast<const T*>(Rv);
+        const T*   dZ   = static_cast<const T*>(Zv);
+        const int* dIdf = idf;
+        if (!on_device)
+        {
+            const int nf = (n - 3) / 2;
+            for (int i = 0; i < m; i++)
+            {
+                if (idf[i] < 1 || idf[i] > nf)
+                {
+                    return fail(CSLAM_ERR_BAD_ARG, "update: idf[%d]=%d outside 1..%d", i, idf[i], nf);
+                }
+            }
+            if ((rc = stage_obs(Zv, idf, m, &dZ, &dIdf)))
+            {
+                return rc;
+            }
+        }
+        if (batch)
+        {
+            return batch_on_device(dZ, dIdf, m, R);
+        }
+        // EKF.cpp:457-479: m successive rank-2 updates, relinearised on the updated state each time
+        for (int i = 0; i < m; i++)
+        {
+            if ((rc = batch_on_device(dZ + 2 * i, dIdf + i, 1, R)))
+            {
+                return rc;
+            }
+        }
+        return CSLAM_OK;
+    }
+
+    // ---------------------------------------------------------------- augment (EKF.cpp:9-91)
+    int augment(const void* Zv, int q, const void* Rv) override
+    {
+        if (q < 0 || !Rv || (q > 0 && !Zv))
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "augment: bad arguments (q=%d)", q);
+        }
+        if (n + 2 * q > ncap)
+        {
+            return fail(CSLAM_ERR_CAPACITY, "augment: %d features would exceed max_landmarks=%d", (n - 3) / 2 + q, nmax);
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const T* Z = static_cast<const T*>(Zv);
+        const T* R = static_cast<const T*>(Rv);
+        for (int i = 0; i < q; i++)
+        {
+            hipLaunchKernelGGL(ekf_augment_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, Z[2 * i],
+                               Z[2 * i + 1], R[0], R[1], R[2], R[3]);
+            CSLAM_HIP_TRY(hipGetLastError());
+            n += 2;
+        }
+        return CSLAM_OK;
+    }
+
+    // ---------------------------------------------------------------- heading (EKF.cpp:328-352)
+    int observe_heading(double phi, int use) override
+    {
+        if (!use)
+        {
+            return CSLAM_OK;
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        // float sigmaPhi = 0.01F * pi / 180.0F; R = pow(sigmaPhi, 2)
+        T sigma = (T)(((double)0.01f * kPi) / 180.0);
+        T R     = sigma * sigma;
+        T* w    = dHead;
+        T* cp2  = dHead + ldp;
+        T* rrow = dHead + 2 * (size_t)ldp;
+        T* scal = dHead + 3 * (size_t)ldp;
+        hipLaunchKernelGGL(ekf_heading_prep_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, (T)phi, R, w, cp2,
+                           rrow, scal);
+        CSLAM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(ekf_heading_apply_kernel<T>, dim3((n + 255) / 256, (n + 15) / 16), dim3(256), 0, stream, dP,
+                           ldp, n, w, cp2, rrow, scal, (T)FLT_MIN);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    int factor_status(int* flags, int clear) override
+    {
+        if (!flags)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "factor_status: null");
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(hFlags, dFlags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        int f = sticky_host;
+        if (hFlags[0] & kFlagZeroed)
+        {
+            f |= CSLAM_FACTOR_ZEROED;
+        }
+        if ((hFlags[0] & kFlagLltFailed) && !(sticky_host & CSLAM_FACTOR_FALLBACK))
+        {
+            f |= CSLAM_FACTOR_SKIPPED; // async mode: the failed factorisation was not followed up
+        }
+        *flags = f;
+        if (clear)
+        {
+            sticky_host = 0;
+            CSLAM_HIP_TRY(hipMemsetAsync(dFlags, 0, 2 * sizeof(int), stream));
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return CSLAM_OK;
+    }
+
+    int debug_last_update(void* PHT, void* S, void* G, void* W1, void* V, int* kout) override
+    {
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const int k = last_k;
+        if (kout)
+        {
+            *kout = k;
+        }
+        if (k == 0)
+        {
+            return CSLAM_OK;
+        }
+        if (PHT)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(PHT, (size_t)n * sizeof(T), dPHT, (size_t)ldp * sizeof(T),
+                                           (size_t)n * sizeof(T), (size_t)k, hipMemcpyDeviceToHost, stream));
+        }
+        if (W1)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(W1, (size_t)n * sizeof(T), dW1, (size_t)ldp * sizeof(T),
+                                           (size_t)n * sizeof(T), (size_t)k, hipMemcpyDeviceToHost, stream));
+        }
+        if (S)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(S, dS, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
+        }
+        if (G)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(G, dG, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
+        }
+        if (V)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(V, dV, (size_t)k * sizeof(T), hipMemcpyDeviceToHost, stream));
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+};
+
+template <>
+int Ekf<float>::launch_downdate(int k)
+{
+    const int tiles = round_up(n, kTile) / kTile;
+    hipLaunchKernelGGL(ekf_downdate_f32, dim3(tiles * tiles), dim3(256), 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    CSLAM_HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+template <>
+int Ekf<double>::launch_downdate(int k)
+{
+    const int tiles_r = round_up(n, kTile) / kTile;
+    const int tiles_c = round_up(n, kTile) / 64;
+    hipLaunchKernelGGL(ekf_downdate_f64, dim3(tiles_r * tiles_c), dim3(256), 0, stream, dP, ldp, dW1, ldp, k, tiles_r);
+    CSLAM_HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+inline EkfBase* B(cslam_ekf_t h)
+{
+    return reinterpret_cast<EkfBase*>(h);
+}
+
+} // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* cslam_last_error(void)
+{
+    return last_error_buf();
+}
+
+int cslam_version(void)
+{
+    return CSLAM_VERSION;
+}
+
+int cslam_device_count(int* count)
+{
+    if (!count)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "device_count: null");
+    }
+    int        c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess)
+    {
+        *count = 0;
+        return fail(CSLAM_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = c;
+    return CSLAM_OK;
+}
+
+int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam_ekf_t* out)
+{
+    if (!out || max_landmarks < 0 || (dtype != CSLAM_F32 && dtype != CSLAM_F64) || (quirks & ~CSLAM_Q_REF_EXACT))
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "ekf_create: bad arguments");
+    }
+    *out  = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c == 0)
+    {
+        return fail(CSLAM_ERR_NO_DEVICE, "ekf_create: no HIP device (this engine has no CPU fallback)");
+    }
+    if (device < 0)
+    {
+        if (hipGetDevice(&device) != hipSuccess)
+        {
+            device = 0;
+        }
+    }
+    if (device >= c)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "ekf_create: device %d of %d", device, c);
+    }
+    EkfBase* b = nullptr;
+    if (dtype == CSLAM_F32)
+    {
+        b = new (std::nothrow) Ekf<float>();
+    }
+    else
+    {
+        b = new (std::nothrow) Ekf<double>();
+    }
+    if (!b)
+    {
+        return fail(CSLAM_ERR_ALLOC, "ekf_create: out of host memory");
+    }
+    b->dtype  = dtype;
+    b->device = device;
+    b->quirks = quirks;
+    b->nmax   = max_landmarks;
+    b->ncap   = 3 + 2 * max_landmarks;
+    b->ldp    = round_up(b->ncap, kTile);
+    b->n      = 3;
+    int rc    = b->init();
+    if (rc)
+    {
+        delete b;
+        return rc;
+    }
+    *out = reinterpret_cast<cslam_ekf_t>(b);
+    return CSLAM_OK;
+}
+
+int cslam_ekf_destroy(cslam_ekf_t h)
+{
+    if (!h)
+    {
+        return CSLAM_OK;
+    }
+    (void)hipSetDevice(B(h)->device);
+    delete B(h);
+    return CSLAM_OK;
+}
+
+#define CSLAM_NEED(h)                                                 \
+    if (!(h))                                                         \
+    {                                                                 \
+        return fail(CSLAM_ERR_BAD_ARG, "%s: null handle", __func__);  \
+    }
+
+int cslam_ekf_set_sync_mode(cslam_ekf_t h, int sync_mode)
+{
+    CSLAM_NEED(h);
+    B(h)->sync_mode = sync_mode ? 1 : 0;
+    return CSLAM_OK;
+}
+
+int cslam_ekf_set_state(cslam_ekf_t h, const void* X, int n, const void* P, int ldp)
+{
+    CSLAM_NEED(h);
+    return B(h)->set_state(X, n, P, ldp);
+}
+
+int cslam_ekf_get_state(cslam_ekf_t h, void* X, void* P, int ldp)
+{
+    CSLAM_NEED(h);
+    return B(h)->get_state(X, P, ldp);
+}
+
+int cslam_ekf_get_x(cslam_ekf_t h, void* X, int capacity)
+{
+    CSLAM_NEED(h);
+    return B(h)->get_x(X, capacity);
+}
+
+int cslam_ekf_get_n(cslam_ekf_t h, int* n)
+{
+    CSLAM_NEED(h);
+    if (!n)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "get_n: null");
+    }
+    *n = B(h)->n;
+    return CSLAM_OK;
+}
+
+int cslam_ekf_trace(cslam_ekf_t h, double* trace)
+{
+    CSLAM_NEED(h);
+    return B(h)->trace(trace);
+}
+
+int cslam_ekf_synchronize(cslam_ekf_t h)
+{
+    CSLAM_NEED(h);
+    CSLAM_HIP_TRY(hipSetDevice(B(h)->device));
+    CSLAM_HIP_TRY(hipStreamSynchronize(B(h)->stream));
+    return CSLAM_OK;
+}
+
+int cslam_ekf_factor_status(cslam_ekf_t h, int* flags, int clear)
+{
+    CSLAM_NEED(h);
+    return B(h)->factor_status(flags, clear);
+}
+
+int cslam_ekf_predict(cslam_ekf_t h, double v, double swa, const void* Q, double wb, double dt)
+{
+    CSLAM_NEED(h);
+    return B(h)->predict(v, swa, Q, wb, dt);
+}
+
+int cslam_ekf_update(cslam_ekf_t h, const void* Z, int m, const void* R, const int* idf, int batch)
+{
+    CSLAM_NEED(h);
+    return B(h)->update(Z, m, R, idf, batch, false);
+}
+
+int cslam_ekf_update_device(cslam_ekf_t h, const void* dZ, int m, const void* R, const int* d_idf, int batch)
+{
+    CSLAM_NEED(h);
+    return B(h)->update(dZ, m, R, d_idf, batch, true);
+}
+
+int cslam_ekf_augment(cslam_ekf_t h, const void* Z, int q, const void* R)
+{
+    CSLAM_NEED(h);
+    return B(h)->augment(Z, q, R);
+}
+
+int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading)
+{
+    CSLAM_NEED(h);
+    return B(h)->observe_heading(phi, use_heading);
+}
+
+int cslam_ekf_set_profiling(cslam_ekf_t h, int on)
+{
+    CSLAM_NEED(h);
+    return B(h)->set_profiling(on);
+}
+
+int cslam_ekf_get_stage_times(cslam_ekf_t h, double* ms_sum, int* launches)
+{
+    CSLAM_NEED(h);
+    return B(h)->get_stage_times(ms_sum, launches);
+}
+
+int cslam_ekf_debug_last_update(cslam_ekf_t h, void* PHT, void* S, void* G, void* W1, void* V, int* k)
+{
+    CSLAM_NEED(h);
+    return B(h)->debug_last_update(PHT, S, G, W1, V, k);
+}
+
+} // extern "C"

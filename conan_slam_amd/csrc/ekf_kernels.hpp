@@ -1,0 +1,929 @@
+// ekf_kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the EKF-SLAM hot path.
+//
+// Data layout in HBM (all column-major, as the reference's Eigen objects):
+//   P    n x n covariance inside an ldp x ldp buffer, ldp = round_up(3+2*Nmax, 128); padding is inert.
+//   X    state, ldp scalars.
+//   PHT  n x k panel, leading dimension ldw = ldp       (slam.h:243)
+//   W1   n x k panel, leading dimension ldw; rows [n, round_up(n,128)) are written as ZERO so that the
+//        downdate can process whole 128-row tiles without bounds checks (P_pad -= 0).
+//   S, G k x k (leading dimension k), V, t length k.
+//
+// Kernels (reference lines they implement):
+//   ekf_gather_kernel    PHT = P*H^T using the 5 non-zero columns of each row of H  (slam.h:243, EKF.cpp:394-395)
+//   ekf_factor_kernel    S = H*PHT+R, symmetrise, LLT, G = inv(L) or inv(L)^T, t = G^T V (slam.h:244-255, EKF.cpp:108-121)
+//   ekf_gain_kernel      W1 = PHT*G, X += W1*t                                       (slam.h:257-259)
+//   ekf_downdate_f32/f64 P -= W1*W1^T on MFMA, LDS-tiled                             (slam.h:260)
+//   ekf_predict_kernel   EKF.cpp:406-455        ekf_augment_kernel   EKF.cpp:28-91
+//   ekf_heading_*        EKF.cpp:328-352 + slam.h:700-725 in exact rank-structured form
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace cslam
+{
+
+constexpr double kPi = 3.14159265358979323846264338327950288; // the reference's std::_Pi_val
+
+constexpr int kFlagLltFailed = 1; // device-side factor flags
+constexpr int kFlagZeroed    = 2;
+
+typedef float  f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float>
+{
+    typedef float4 type;
+};
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------------
+__device__ inline float  dsqrt(float x) { return sqrtf(x); }
+__device__ inline double dsqrt(double x) { return sqrt(x); }
+__device__ inline float  datan2(float y, float x) { return atan2f(y, x); }
+__device__ inline double datan2(double y, double x) { return atan2(y, x); }
+__device__ inline float  dsin(float x) { return sinf(x); }
+__device__ inline double dsin(double x) { return sin(x); }
+__device__ inline float  dcos(float x) { return cosf(x); }
+__device__ inline double dcos(double x) { return cos(x); }
+__device__ inline float  dfmod(float x, float y) { return fmodf(x, y); }
+__device__ inline double dfmod(double x, double y) { return fmod(x, y); }
+__device__ inline bool   dfinite(float x) { return isfinite(x); }
+__device__ inline bool   dfinite(double x) { return isfinite(x); }
+
+// slam.h:816-829 -- fmod at the scalar's precision, +-2pi corrections compared and added in double
+template <typename T>
+__device__ inline T pi2pi(T angle)
+{
+    angle = dfmod(angle, (T)(2.0 * kPi));
+    if ((double)angle > kPi)
+    {
+        angle = (T)((double)angle - (2.0 * kPi));
+    }
+    if ((double)angle < -kPi)
+    {
+        angle = (T)((double)angle + (2.0 * kPi));
+    }
+    return angle;
+}
+
+// EKF.cpp:354-404 for one observation. coef[0..4] = row 0 of H at columns {0,1,2,fx,fx+1},
+// coef[5..9] = row 1; v = innovation (EKF.cpp:117-118, bearing wrapped); fx = 0-based index of the
+// feature's x in the state (= fpos-1 of the reference).
+template <typename T>
+__device__ inline void observe_model(const T* __restrict__ X, int n, int idf, T zr, T zb, T* coef, T* v, int* fx)
+{
+    int f = 3 + 2 * idf - 2;
+    *fx   = f;
+    if (n > 3)
+    {
+        T dx  = X[f] - X[0];
+        T dy  = X[f + 1] - X[1];
+        T d2  = dx * dx + dy * dy;
+        T d   = dsqrt(d2);
+        T xd  = dx / d;
+        T yd  = dy / d;
+        T xd2 = dx / d2;
+        T yd2 = dy / d2;
+        coef[0] = -xd;
+        coef[1] = -yd;
+        coef[2] = (T)0;
+        coef[3] = xd;
+        coef[4] = yd;
+        coef[5] = yd2;
+        coef[6] = -xd2;
+        coef[7] = (T)-1;
+        coef[8] = -yd2;
+        coef[9] = xd2;
+        v[0]    = zr - d;
+        v[1]    = pi2pi<T>(zb - (datan2(dy, dx) - X[2]));
+    }
+    else
+    {
+        for (int i = 0; i < 10; i++)
+        {
+            coef[i] = (T)0;
+        }
+        v[0] = zr;
+        v[1] = pi2pi<T>(zb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: PHT = P * H^T   (slam.h:243).  Row i of H^T's product only touches columns {0,1,2,fx,fx+1} of P
+// (EKF.cpp:394-395), which in column-major P are contiguous columns -> fully coalesced reads.
+// grid = (ceil(n/256), ceil(m/kGatherObs)), block = 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGatherObs = 8;
+
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X, const T* __restrict__ P, int ldp,
+                                                          int n, const T* __restrict__ Z, const int* __restrict__ idf,
+                                                          int m, T* __restrict__ PHT, int ldw)
+{
+    __shared__ T   s_coef[kGatherObs * 10];
+    __shared__ int s_fx[kGatherObs];
+    int            o0 = blockIdx.y * kGatherObs;
+    int            no = min(kGatherObs, m - o0);
+    if ((int)threadIdx.x < no)
+    {
+        T v[2];
+        int o = o0 + threadIdx.x;
+        observe_model<T>(X, n, idf[o], Z[2 * o], Z[2 * o + 1], &s_coef[threadIdx.x * 10], v, &s_fx[threadIdx.x]);
+    }
+    __syncthreads();
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    T p0 = P[(size_t)0 * ldp + i], p1 = P[(size_t)1 * ldp + i], p2 = P[(size_t)2 * ldp + i];
+    for (int oo = 0; oo < no; oo++)
+    {
+        const T* c  = &s_coef[oo * 10];
+        int      fx = s_fx[oo];
+        T        a  = P[(size_t)fx * ldp + i];
+        T        b  = P[(size_t)(fx + 1) * ldp + i];
+        // same summation order as the dense product: columns 0,1,2,fx,fx+1 ascending
+        T s0 = p0 * c[0];
+        s0 += p1 * c[1];
+        s0 += p2 * c[2];
+        s0 += a * c[3];
+        s0 += b * c[4];
+        T s1 = p0 * c[5];
+        s1 += p1 * c[6];
+        s1 += p2 * c[7];
+        s1 += a * c[8];
+        s1 += b * c[9];
+        int col = 2 * (o0 + oo);
+        PHT[(size_t)col * ldw + i]       = s0;
+        PHT[(size_t)(col + 1) * ldw + i] = s1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2+K3: one workgroup.  S = H*PHT + RR (slam.h:244), symmetrise (247), lower Cholesky (250 / 417-423),
+// G = inv(L) [REF_EXACT] or inv(L)^T [TEXTBOOK] (251 + quirk #1), non-finite -> zeros (252-255),
+// t = G^T V.  S and G live in LDS when they fit (lds_ld = k+1 to spread banks), else in global scratch.
+// Outputs: dS (symmetrised S), dG (k x k), dGt (= G^T, so that the gain kernel reads rows of G
+// contiguously), dV, dt, flags[0] |= code (sticky), flags[1] = code.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFactorThreads = 256;
+
+template <typename T>
+struct FactorArgs
+{
+    const T*   X;
+    int        n;
+    const T*   Z;
+    const int* idf;
+    int        m;
+    T          R[4];
+    const T*   PHT;
+    int        ldw;
+    T*         dS;
+    T*         dG;
+    T*         dGt;
+    T*         dV;
+    T*         dt;
+    int*       flags;
+    T*         scratchS; // global k x (k+1) scratch used when LDS is too small
+    T*         scratchG;
+    int        lds_S; // 1: S in LDS
+    int        lds_G; // 1: G in LDS
+    int        textbook;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kFactorThreads) ekf_factor_kernel(FactorArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int     k   = 2 * a.m;
+    const int     ld  = k + 1;
+    const int     tid = threadIdx.x;
+    const int     nth = kFactorThreads;
+    T*            sm  = reinterpret_cast<T*>(smem_raw);
+    size_t        off = 0;
+    T*            S   = a.lds_S ? (sm + off) : a.scratchS;
+    off += a.lds_S ? (size_t)k * ld : 0;
+    T* G = a.lds_G ? (sm + off) : a.scratchG;
+    off += a.lds_G ? (size_t)k * ld : 0;
+    T* coef = sm + off;
+    off += (size_t)a.m * 10;
+    T* V = sm + off;
+    off += (size_t)k;
+    int* fxs  = reinterpret_cast<int*>(sm + off);
+    int* sflg = fxs + a.m; // [0] llt failed, [1] non-finite
+
+    if (tid == 0)
+    {
+        sflg[0] = 0;
+        sflg[1] = 0;
+    }
+    // observation models and innovations (EKF.cpp:108-121)
+    for (int o = tid; o < a.m; o += nth)
+    {
+        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    __syncthreads();
+    // S = H*PHT + RR : 5-term sums in ascending column order, then + R on the 2x2 diagonal blocks
+    for (int e = tid; e < k * k; e += nth)
+    {
+        int      r  = e % k;
+        int      c  = e / k;
+        int      ob = r >> 1, ra = r & 1;
+        const T* cf = &coef[ob * 10 + ra * 5];
+        int      fx = fxs[ob];
+        const T* ph = a.PHT + (size_t)c * a.ldw;
+        T        s  = cf[0] * ph[0];
+        s += cf[1] * ph[1];
+        s += cf[2] * ph[2];
+        s += cf[3] * ph[fx];
+        s += cf[4] * ph[fx + 1];
+        T rr = ((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0;
+        S[r + (size_t)c * ld] = s + rr;
+    }
+    __syncthreads();
+    // makeSymmetric (slam.h:776-779): each unordered pair owned by one thread
+    for (int e = tid; e < k * k; e += nth)
+    {
+        int r = e % k;
+        int c = e / k;
+        if (r > c)
+        {
+            T v                    = (S[r + (size_t)c * ld] + S[c + (size_t)r * ld]) * (T)0.5;
+            S[r + (size_t)c * ld] = v;
+            S[c + (size_t)r * ld] = v;
+        }
+        else if (r == c)
+        {
+            T d                    = S[r + (size_t)c * ld];
+            S[r + (size_t)c * ld] = (d + d) * (T)0.5;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < k * k; e += nth)
+    {
+        a.dS[e] = S[(e % k) + (size_t)(e / k) * ld];
+    }
+    __syncthreads();
+    // right-looking lower Cholesky in place (Eigen::LLT reads the lower triangle only); a pivot <= 0
+    // is the LLT failure of slam.h:421
+    for (int j = 0; j < k; j++)
+    {
+        if (tid == 0)
+        {
+            T d = S[j + (size_t)j * ld];
+            if (d <= (T)0)
+            {
+                sflg[0] = 1;
+            }
+            else
+            {
+                S[j + (size_t)j * ld] = dsqrt(d);
+            }
+        }
+        __syncthreads();
+        if (sflg[0])
+        {
+            break;
+        }
+        T dj = S[j + (size_t)j * ld];
+        for (int r = j + 1 + tid; r < k; r += nth)
+        {
+            S[r + (size_t)j * ld] = S[r + (size_t)j * ld] / dj;
+        }
+        __syncthreads();
+        int cnt = k - j - 1;
+        for (int e = tid; e < cnt * cnt; e += nth)
+        {
+            int c = j + 1 + e / cnt;
+            int r = j + 1 + e % cnt;
+            if (r >= c)
+            {
+                S[r + (size_t)c * ld] -= S[r + (size_t)j * ld] * S[c + (size_t)j * ld];
+            }
+        }
+        __syncthreads();
+    }
+    const bool failed = (sflg[0] != 0);
+    // G = inv(L): one column per thread, uniform loops (G is zero above its diagonal, so the dot
+    // products may start at q = 0 and every lane reads the same L element -> LDS broadcast)
+    if (!failed)
+    {
+        for (int c = tid; c < k; c += nth)
+        {
+            T* g = G + (size_t)c * ld;
+            for (int r = 0; r < k; r++)
+            {
+                T s = (T)0;
+                for (int q = 0; q < r; q++)
+                {
+                    s += S[r + (size_t)q * ld] * g[q];
+                }
+                T e  = (r == c) ? (T)1 : (T)0;
+                g[r] = (r < c) ? (T)0 : (e - s) / S[r + (size_t)r * ld];
+            }
+        }
+    }
+    __syncthreads();
+    // finite check (slam.h:252-255)
+    if (!failed)
+    {
+        int bad = 0;
+        for (int e = tid; e < k * k; e += nth)
+        {
+            bad |= !dfinite(G[(e % k) + (size_t)(e / k) * ld]);
+        }
+        if (bad)
+        {
+            atomicOr(&sflg[1], 1);
+        }
+    }
+    __syncthreads();
+    const bool zero = failed || (sflg[1] != 0);
+    // write G in its final orientation (and its transpose), t = G^T V
+    for (int e = tid; e < k * k; e += nth)
+    {
+        int r = e % k, c = e / k;
+        T   g = (T)0;
+        if (!zero)
+        {
+            g = a.textbook ? G[c + (size_t)r * ld] : G[r + (size_t)c * ld];
+        }
+        a.dG[r + (size_t)c * k]  = g;
+        a.dGt[c + (size_t)r * k] = g;
+    }
+    __syncthreads();
+    for (int c = tid; c < k; c += nth)
+    {
+        T s = (T)0;
+        if (!zero)
+        {
+            for (int r = 0; r < k; r++)
+            {
+                T g = a.textbook ? G[c + (size_t)r * ld] : G[r + (size_t)c * ld];
+                s += g * V[r];
+            }
+        }
+        a.dt[c] = s;
+    }
+    if (tid == 0)
+    {
+        int code = (failed ? kFlagLltFailed : 0) | ((!failed && sflg[1]) ? kFlagZeroed : 0);
+        a.flags[1] = code;
+        if (code)
+        {
+            atomicOr(&a.flags[0], code);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: W1 = PHT * G (slam.h:257) and X += W1 * t (slam.h:258-259 with W never formed: W*V = W1*(G^T V)).
+// block = 256 threads = 64 rows x 4 column groups; Gt (= G^T, so row q of G is contiguous) is read
+// through wave-uniform addresses (one wave = one column group).  Rows [n, n_pad) of W1 are zeroed.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGainCols = 16; // columns per thread per pass
+
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_gain_kernel(const T* __restrict__ PHT, int ldw, int n, int n_pad, int k,
+                                                        const T* __restrict__ Gt, const T* __restrict__ t,
+                                                        T* __restrict__ W1, T* __restrict__ X)
+{
+    __shared__ T s_part[4][64];
+    const int    ri = threadIdx.x & 63;
+    const int    cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int    i  = blockIdx.x * 64 + ri;
+    const bool   in = (i < n);
+    T            xs = (T)0;
+    for (int cbase = 0; cbase < k; cbase += 4 * kGainCols)
+    {
+        const int c0 = cbase + cg * kGainCols;
+        T         acc[kGainCols];
+#pragma unroll
+        for (int cc = 0; cc < kGainCols; cc++)
+        {
+            acc[cc] = (T)0;
+        }
+        if (c0 < k)
+        {
+            for (int q = 0; q < k; q++)
+            {
+                T        p  = in ? PHT[(size_t)q * ldw + i] : (T)0;
+                const T* gr = Gt + (size_t)q * k + c0; // G[q, c0..]
+#pragma unroll
+                for (int cc = 0; cc < kGainCols; cc++)
+                {
+                    T g = (c0 + cc < k) ? gr[cc] : (T)0;
+                    acc[cc] += p * g;
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < kGainCols; cc++)
+            {
+                if (c0 + cc < k)
+                {
+                    if (i < n_pad)
+                    {
+                        W1[(size_t)(c0 + cc) * ldw + i] = in ? acc[cc] : (T)0;
+                    }
+                    xs += acc[cc] * t[c0 + cc];
+                }
+            }
+        }
+    }
+    s_part[cg][ri] = xs;
+    __syncthreads();
+    if (cg == 0 && in)
+    {
+        T s = s_part[0][ri];
+        s += s_part[1][ri];
+        s += s_part[2][ri];
+        s += s_part[3][ri];
+        X[i] = X[i] + s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f32): P -= W1 * W1^T  (slam.h:260) -- the P-GEMM.
+// Workgroup = 4 waves, tile = 128 rows x 128 cols of P; wave w owns columns [32w, 32w+32) and all 128
+// rows as FOUR interleaved 32x32 MFMA tiles: MFMA column index j (the lane) <-> P rows 4j+b, b = 0..3,
+// so that every global access of P is a 16-byte-per-lane load/store of 4 consecutive rows (512
+// contiguous bytes per half-wave) and the B operand of all four tiles is one ds_read_b128.
+// v_mfma_f32_32x32x2_f32: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
+// D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31] in register r.  Here i <-> P column, j <-> P row.
+// The product is accumulated from zero and subtracted once, as the reference does (temporary, then P - tmp).
+// W1 panels of the tile's rows and columns are staged through LDS in k-chunks of KC.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDownKC = 32;
+
+__global__ void __launch_bounds__(256, 3) ekf_downdate_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
+                                                            int ldw, int k, int tiles)
+{
+    __shared__ __attribute__((aligned(16))) float s_pan[2 * kDownKC * 128]; // [0]: row panel, [1]: column panel
+    float* sB = s_pan;
+    float* sA = s_pan + kDownKC * 128;
+
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int tj   = blockIdx.x / tiles; // column tile (shared by consecutive workgroups)
+    const int ti   = blockIdx.x % tiles; // row tile
+    const int row0 = ti * 128;
+    const int col0 = tj * 128;
+
+    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+
+    for (int k0 = 0; k0 < k; k0 += kDownKC)
+    {
+        const int kc = min(kDownKC, k - k0);
+        if (k0 > 0)
+        {
+            __syncthreads();
+        }
+        for (int id = tid; id < kc * 32; id += 256)
+        {
+            const int    kk = id >> 5;
+            const int    r4 = (id & 31) * 4;
+            const float* w  = W1 + (size_t)(k0 + kk) * ldw;
+            float4       vb = *reinterpret_cast<const float4*>(w + row0 + r4);
+            float4       va = *reinterpret_cast<const float4*>(w + col0 + r4);
+            *reinterpret_cast<float4*>(&sB[kk * 128 + r4]) = vb;
+            *reinterpret_cast<float4*>(&sA[kk * 128 + r4]) = va;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < kc; kk += 2)
+        {
+            const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + lh) * 128 + 4 * lj]);
+            const float  a = sA[(kk + lh) * 128 + wave * 32 + lj];
+            acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+            acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+            acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+            acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+        }
+    }
+    // epilogue: all loads of a half-tile are issued before the first store, so that 8 x 1 KiB per wave
+    // are in flight (a load placed after a store to the same array would be serialised behind it)
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+    {
+        float4* ptr[8];
+        float4  v[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++)
+        {
+            const int r   = half * 8 + rr;
+            const int col = col0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            ptr[rr]       = reinterpret_cast<float4*>(P + (size_t)col * ldp + row0 + 4 * lj);
+            v[rr]         = *ptr[rr];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++)
+        {
+            const int r = half * 8 + rr;
+            v[rr].x -= acc0[r];
+            v[rr].y -= acc1[r];
+            v[rr].z -= acc2[r];
+            v[rr].w -= acc3[r];
+            *ptr[rr] = v[rr];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f64): same structure on v_mfma_f64_16x16x4_f64.
+// A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D[i = (lane>>4) + 4*g][j = lane&15], g = 0..3.
+// i <-> P column, j <-> P rows 2j+b (b = 0,1: one 16-byte double2 per lane).
+// Workgroup tile = 128 rows x 64 cols; wave w owns rows [32w, 32w+32) and all 64 columns (4 column blocks).
+// ------------------------------------------------------------------------------------------------
+constexpr int kDownKC64 = 16;
+
+__global__ void __launch_bounds__(256, 3) ekf_downdate_f64(double* __restrict__ P, int ldp,
+                                                            const double* __restrict__ W1, int ldw, int k, int tiles_r)
+{
+    __shared__ __attribute__((aligned(16))) double s_pan[kDownKC64 * (128 + 64)];
+    double* sB = s_pan;                   // [kc][128] rows
+    double* sA = s_pan + kDownKC64 * 128; // [kc][64]  columns
+
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int lj   = lane & 15;
+    const int lq   = lane >> 4;
+    const int tj   = blockIdx.x / tiles_r; // column tile of 64
+    const int ti   = blockIdx.x % tiles_r; // row tile of 128
+    const int row0 = ti * 128;
+    const int col0 = tj * 64;
+
+    f64x4 acc[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+    {
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++)
+        {
+            acc[b][cb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    for (int k0 = 0; k0 < k; k0 += kDownKC64)
+    {
+        const int kc = min(kDownKC64, k - k0);
+        if (k0 > 0)
+        {
+            __syncthreads();
+        }
+        // row panel: kc x 128 doubles = kc*64 double2 ; column panel: kc x 64 doubles = kc*32 double2
+        for (int id = tid; id < kc * 64; id += 256)
+        {
+            const int     kk = id >> 6;
+            const int     r2 = (id & 63) * 2;
+            const double* w  = W1 + (size_t)(k0 + kk) * ldw;
+            *reinterpret_cast<double2*>(&sB[kk * 128 + r2]) = *reinterpret_cast<const double2*>(w + row0 + r2);
+        }
+        for (int id = tid; id < kc * 32; id += 256)
+        {
+            const int     kk = id >> 5;
+            const int     r2 = (id & 31) * 2;
+            const double* w  = W1 + (size_t)(k0 + kk) * ldw;
+            *reinterpret_cast<double2*>(&sA[kk * 64 + r2]) = *reinterpret_cast<const double2*>(w + col0 + r2);
+        }
+        __syncthreads();
+        // k advances by 4 per MFMA; when kc is not a multiple of 4 (k = 2 mod 4) the tail lanes feed zeros
+        for (int kk = 0; kk < kc; kk += 4)
+        {
+            const int     kq  = kk + lq;
+            const bool    ok  = (kq < kc);
+            const double2 b   = ok ? *reinterpret_cast<const double2*>(&sB[kq * 128 + wave * 32 + 2 * lj])
+                                   : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++)
+            {
+                const double a = ok ? sA[kq * 64 + cb * 16 + lj] : 0.0;
+                acc[0][cb]     = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.x, acc[0][cb], 0, 0, 0);
+                acc[1][cb]     = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.y, acc[1][cb], 0, 0, 0);
+            }
+        }
+    }
+    {
+        double2* ptr[16];
+        double2  v[16];
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++)
+        {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                const int col   = col0 + cb * 16 + lq + 4 * g;
+                ptr[cb * 4 + g] = reinterpret_cast<double2*>(P + (size_t)col * ldp + row0 + wave * 32 + 2 * lj);
+                v[cb * 4 + g]   = *ptr[cb * 4 + g];
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++)
+        {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                v[cb * 4 + g].x -= acc[0][cb][g];
+                v[cb * 4 + g].y -= acc[1][cb][g];
+                *ptr[cb * 4 + g] = v[cb * 4 + g];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: predict (EKF.cpp:406-455).  One workgroup: the barrier orders every read of the old pose and old
+// Pvv before they are overwritten.  stripe_w = n-4 (REF_EXACT, quirk #2) or n-3 (TEXTBOOK).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) ekf_predict_kernel(T* __restrict__ X, T* __restrict__ P, int ldp, int n, T v,
+                                                            T swa, T q00, T q10, T q01, T q11, T wb, T dt,
+                                                            int stripe_w)
+{
+    __shared__ T s_gv[9];
+    __shared__ T s_pvv[9];
+    __shared__ T s_pose[3];
+    const int    tid = threadIdx.x;
+    if (tid == 0)
+    {
+        T phi = X[2];
+        T s = dsin(swa + phi), c = dcos(swa + phi);
+        T Gv[9] = {(T)1, (T)0, (T)0, (T)0, (T)1, (T)0, -v * dt * s, v * dt * c, (T)1}; // column-major
+        T Gu[6] = {dt * c, dt * s, dt * dsin(swa) / wb, -v * dt * s, v * dt * c, v * dt * dcos(swa) / wb};
+        T Q[4]  = {q00, q10, q01, q11};
+        T Pv[9], t1[9], t2[9];
+        for (int cc = 0; cc < 3; cc++)
+        {
+            for (int r = 0; r < 3; r++)
+            {
+                Pv[r + 3 * cc] = P[(size_t)cc * ldp + r];
+            }
+        }
+        for (int cc = 0; cc < 3; cc++) // t1 = Gv*Pvv
+        {
+            for (int r = 0; r < 3; r++)
+            {
+                T acc = (T)0;
+                for (int l = 0; l < 3; l++)
+                {
+                    acc += Gv[r + 3 * l] * Pv[l + 3 * cc];
+                }
+                t1[r + 3 * cc] = acc;
+            }
+        }
+        for (int cc = 0; cc < 3; cc++) // t2 = t1*Gv^T
+        {
+            for (int r = 0; r < 3; r++)
+            {
+                T acc = (T)0;
+                for (int l = 0; l < 3; l++)
+                {
+                    acc += t1[r + 3 * l] * Gv[cc + 3 * l];
+                }
+                t2[r + 3 * cc] = acc;
+            }
+        }
+        T GuQ[6];
+        for (int cc = 0; cc < 2; cc++)
+        {
+            for (int r = 0; r < 3; r++)
+            {
+                T acc = (T)0;
+                for (int l = 0; l < 2; l++)
+                {
+                    acc += Gu[r + 3 * l] * Q[l + 2 * cc];
+                }
+                GuQ[r + 3 * cc] = acc;
+            }
+        }
+        for (int cc = 0; cc < 3; cc++)
+        {
+            for (int r = 0; r < 3; r++)
+            {
+                T acc = (T)0;
+                for (int l = 0; l < 2; l++)
+                {
+                    acc += GuQ[r + 3 * l] * Gu[cc + 3 * l];
+                }
+                s_pvv[r + 3 * cc] = t2[r + 3 * cc] + acc;
+            }
+        }
+        for (int e = 0; e < 9; e++)
+        {
+            s_gv[e] = Gv[e];
+        }
+        s_pose[0] = X[0] + v * dt * c;
+        s_pose[1] = X[1] + v * dt * s;
+        s_pose[2] = pi2pi<T>(X[2] + v * dt * dsin(swa) / wb);
+    }
+    __syncthreads();
+    // cross-covariance stripe: P[0:3, 3:3+w] = Gv * stripe, mirrored (EKF.cpp:442-443)
+    for (int j = tid; j < stripe_w; j += blockDim.x)
+    {
+        const int c  = 3 + j;
+        T         a0 = P[(size_t)c * ldp + 0], a1 = P[(size_t)c * ldp + 1], a2 = P[(size_t)c * ldp + 2];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            acc += s_gv[r + 0] * a0;
+            acc += s_gv[r + 3] * a1;
+            acc += s_gv[r + 6] * a2;
+            P[(size_t)c * ldp + r] = acc;
+            P[(size_t)r * ldp + c] = acc;
+        }
+    }
+    if (tid < 9)
+    {
+        P[(size_t)(tid / 3) * ldp + (tid % 3)] = s_pvv[tid];
+    }
+    if (tid < 3)
+    {
+        X[tid] = s_pose[tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: augment by one feature (EKF.cpp:28-91), O(n): the covariance buffer is preallocated, so the
+// reference's copy-resize-zero-copy (EKF.cpp:67-71) disappears.  One workgroup.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) ekf_augment_kernel(T* __restrict__ X, T* __restrict__ P, int ldp, int len, T r,
+                                                            T b, T r00, T r10, T r01, T r11)
+{
+    __shared__ T s_gv[6];
+    const int    tid = threadIdx.x;
+    if (tid == 0)
+    {
+        T s = dsin(X[2] + b), c = dcos(X[2] + b);
+        X[len]     = X[0] + (r * c);
+        X[len + 1] = X[1] + (r * s);
+        T Gv[6] = {(T)1, (T)0, (T)0, (T)1, -r * s, r * c}; // 2x3 column-major
+        T Gz[4] = {c, s, -r * s, r * c};
+        T R[4]  = {r00, r10, r01, r11};
+        T GvP[6];
+        for (int cc = 0; cc < 3; cc++)
+        {
+            for (int rr = 0; rr < 2; rr++)
+            {
+                T acc = (T)0;
+                for (int l = 0; l < 3; l++)
+                {
+                    acc += Gv[rr + 2 * l] * P[(size_t)cc * ldp + l];
+                }
+                GvP[rr + 2 * cc] = acc;
+            }
+        }
+        T GzR[4];
+        for (int cc = 0; cc < 2; cc++)
+        {
+            for (int rr = 0; rr < 2; rr++)
+            {
+                T acc = (T)0;
+                for (int l = 0; l < 2; l++)
+                {
+                    acc += Gz[rr + 2 * l] * R[l + 2 * cc];
+                }
+                GzR[rr + 2 * cc] = acc;
+            }
+        }
+        for (int cc = 0; cc < 2; cc++)
+        {
+            for (int rr = 0; rr < 2; rr++)
+            {
+                T a1 = (T)0;
+                for (int l = 0; l < 3; l++)
+                {
+                    a1 += GvP[rr + 2 * l] * Gv[cc + 2 * l];
+                }
+                T a2 = (T)0;
+                for (int l = 0; l < 2; l++)
+                {
+                    a2 += GzR[rr + 2 * l] * Gz[cc + 2 * l];
+                }
+                P[(size_t)(len + cc) * ldp + len + rr] = a1 + a2; // EKF.cpp:74
+            }
+        }
+        for (int e = 0; e < 6; e++)
+        {
+            s_gv[e] = Gv[e];
+        }
+    }
+    __syncthreads();
+    // EKF.cpp:77-78, 83-84: new rows = Gv * P[0:3, 0:len], mirrored into the new columns
+    for (int j = tid; j < len; j += blockDim.x)
+    {
+        T a0 = P[(size_t)j * ldp + 0], a1 = P[(size_t)j * ldp + 1], a2 = P[(size_t)j * ldp + 2];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+        {
+            T acc = (T)0;
+            acc += s_gv[rr + 0] * a0;
+            acc += s_gv[rr + 2] * a1;
+            acc += s_gv[rr + 4] * a2;
+            P[(size_t)j * ldp + len + rr]   = acc;
+            P[(size_t)(len + rr) * ldp + j] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: heading observation (EKF.cpp:328-352 -> josephUpdate slam.h:700-725) with H = e_2^T.
+// The dense Joseph form C*P*C^T + W*R*W^T, C = I - W*H, is evaluated exactly but using the structure of
+// C (identity except column 2):   CP[i,j] = P[i,j] - W[i]*P[2,j];   (CP*C^T)[i,j] = CP[i,j] - CP[i,2]*W[j]
+// for j != 2 and CP[i,2]*(1 - W[2]) for j == 2;   plus (W[i]*R)*W[j];   plus FLT_MIN on the diagonal
+// (slam.h:719).  O(n^2) instead of the reference's two n^3 GEMMs.
+//   prep kernel (one workgroup): p = P[:,2], r = P[2,:], S = P22 + R, W = p * (1/S), X += W*V, scratch.
+//   apply kernel: elementwise over P.
+// scratch layout: w[ldp], cp2[ldp] (= p - W*P22), r[ldp], then scalars {R, 1-W[2]}.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) ekf_heading_prep_kernel(T* __restrict__ X, const T* __restrict__ P, int ldp,
+                                                                 int n, T phi, T R, T* __restrict__ w,
+                                                                 T* __restrict__ cp2, T* __restrict__ rrow,
+                                                                 T* __restrict__ scal)
+{
+    __shared__ T s_v, s_si, s_p22, s_omw2;
+    const int    tid = threadIdx.x;
+    if (tid == 0)
+    {
+        s_v    = pi2pi<T>(phi - X[2]);
+        T p22  = P[(size_t)2 * ldp + 2];
+        T S    = p22 + R;  // H*PHT + R
+        s_si   = (T)1 / S; // S.inverse(); makeSymmetric of a 1x1 changes nothing
+        s_p22  = p22;
+        s_omw2 = (T)1 - p22 * s_si; // C[2,2] = 1 - W[2]
+    }
+    __syncthreads();
+    const T V = s_v, SI = s_si, p22 = s_p22, omw2 = s_omw2;
+    for (int i = tid; i < n; i += blockDim.x)
+    {
+        T pi_   = P[(size_t)2 * ldp + i]; // column 2 (PHT = P*H^T)
+        T wi    = pi_ * SI;               // W = PHT*SI
+        w[i]    = wi;
+        cp2[i]  = (i == 2) ? omw2 * p22 : pi_ - wi * p22; // (C*P)[i,2]; row 2 of C is (1-W[2]) e_2^T
+        rrow[i] = P[(size_t)i * ldp + 2];                 // row 2
+        X[i]    = X[i] + wi * V;
+    }
+    if (tid == 0)
+    {
+        scal[0] = R;
+        scal[1] = omw2;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_heading_apply_kernel(T* __restrict__ P, int ldp, int n,
+                                                                 const T* __restrict__ w, const T* __restrict__ cp2,
+                                                                 const T* __restrict__ rrow,
+                                                                 const T* __restrict__ scal, T tiny)
+{
+    // block: 256 rows x 16 columns
+    const int i  = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * 16;
+    if (i >= n)
+    {
+        return;
+    }
+    const T wi = w[i], ci2 = cp2[i];
+    const T R = scal[0], omw2 = scal[1];
+    const T wir = wi * R;
+    for (int jj = 0; jj < 16; jj++)
+    {
+        const int j = j0 + jj;
+        if (j >= n)
+        {
+            break;
+        }
+        T* p   = P + (size_t)j * ldp + i;
+        T  cp  = (i == 2) ? omw2 * rrow[j] : *p - wi * rrow[j]; // (C*P)[i,j]
+        T  wj  = w[j];
+        T  out;
+        if (j == 2)
+        {
+            out = ci2 * omw2;
+        }
+        else
+        {
+            out = cp + ci2 * (-wj);
+        }
+        out = out + wir * wj;
+        if (i == j)
+        {
+            out = out + tiny;
+        }
+        *p = out;
+    }
+}
+
+} // namespace cslam

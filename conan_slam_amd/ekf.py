@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's EKF back-end over the C ABI (include/cslam.h).
+
+`EKF` offers the reference's call surface for the hot path -- predict / update / augment /
+observeHeading (slam.h:841-847, 938-943, 190-191, 788; EKF.cpp) -- with the same argument meaning:
+feature indices are 1-based, Z is 2 x m (range; bearing), Q and R are 2 x 2.  The difference to the
+reference is ownership: X and P live on the GPU inside the handle instead of being passed by reference
+into every call; `X` / `P` properties (or get_state) download them.
+
+All arithmetic happens in the HIP library; this file only marshals pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (F32, F64, Q_REF_EXACT, Q_TEXTBOOK, check)
+
+
+def _vp(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class EKF:
+    def __init__(self, max_landmarks: int, dtype=np.float32, device: int = -1, quirks: int = Q_REF_EXACT,
+                 sync_mode: bool = True):
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        self._L = _capi.lib()
+        self._h = C.c_void_p(None)
+        code = F32 if self.dtype == np.float32 else F64
+        check(self._L.cslam_ekf_create(C.c_int(max_landmarks), C.c_int(code), C.c_int(device), C.c_int(quirks),
+                                       C.byref(self._h)))
+        self.max_landmarks = max_landmarks
+        self.quirks = quirks
+        if not sync_mode:
+            self.set_sync_mode(False)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.cslam_ekf_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ helpers
+    def _arr(self, a, shape=None):
+        a = np.ascontiguousarray(np.asarray(a, dtype=self.dtype).reshape(-1, order="F"))
+        return a
+
+    def _mat22(self, M):
+        return np.asfortranarray(np.asarray(M, dtype=self.dtype).reshape(2, 2))
+
+    def set_sync_mode(self, on: bool):
+        check(self._L.cslam_ekf_set_sync_mode(self._h, C.c_int(1 if on else 0)))
+
+    # ------------------------------------------------------------------ state
+    @property
+    def n(self) -> int:
+        v = C.c_int(0)
+        check(self._L.cslam_ekf_get_n(self._h, C.byref(v)))
+        return v.value
+
+    def set_state(self, X, P):
+        X = np.ascontiguousarray(X, dtype=self.dtype)
+        P = np.asfortranarray(P, dtype=self.dtype)
+        n = X.shape[0]
+        assert P.shape == (n, n)
+        check(self._L.cslam_ekf_set_state(self._h, _vp(X), C.c_int(n), _vp(P), C.c_int(n)))
+
+    def get_state(self):
+        n = self.n
+        X = np.zeros(n, dtype=self.dtype)
+        P = np.zeros((n, n), dtype=self.dtype, order="F")
+        check(self._L.cslam_ekf_get_state(self._h, _vp(X), _vp(P), C.c_int(n)))
+        return X, P
+
+    def get_x(self):
+        n = self.n
+        X = np.zeros(n, dtype=self.dtype)
+        check(self._L.cslam_ekf_get_x(self._h, _vp(X), C.c_int(n)))
+        return X
+
+    def get_p(self):
+        return self.get_state()[1]
+
+    X = property(get_x)
+    P = property(get_p)
+
+    def trace(self) -> float:
+        t = C.c_double(0.0)
+        check(self._L.cslam_ekf_trace(self._h, C.byref(t)))
+        return t.value
+
+    def synchronize(self):
+        check(self._L.cslam_ekf_synchronize(self._h))
+
+    def factor_status(self, clear: bool = False) -> int:
+        f = C.c_int(0)
+        check(self._L.cslam_ekf_factor_status(self._h, C.byref(f), C.c_int(1 if clear else 0)))
+        return f.value
+
+    # ------------------------------------------------------------------ the hot path
+    def predict(self, v, swa, Q, wb, dt):
+        """Slam::predict(X, P, v, swa, Q, wb, dt) -- EKF.cpp:406-455."""
+        Q = self._mat22(Q)
+        check(self._L.cslam_ekf_predict(self._h, C.c_double(float(v)), C.c_double(float(swa)), _vp(Q),
+                                        C.c_double(float(wb)), C.c_double(float(dt))))
+
+    def update(self, Z, R, idf, batch: bool = False):
+        """Slam::update(X, P, Z, R, idf, batch) -- EKF.cpp:481-496 (batch defaults to false, slam.h:943)."""
+        Z = np.asarray(Z, dtype=self.dtype)
+        m = 0 if Z.size == 0 else Z.reshape(2, -1, order="F").shape[1]
+        Zc = self._arr(Z) if m else np.zeros(2, dtype=self.dtype)
+        R = self._mat22(R)
+        idf = np.ascontiguousarray(idf, dtype=np.int32)
+        assert idf.shape[0] == m
+        idp = idf.ctypes.data_as(C.c_void_p) if m else None
+        check(self._L.cslam_ekf_update(self._h, _vp(Zc), C.c_int(m), _vp(R), idp, C.c_int(1 if batch else 0)))
+
+    def update_device(self, dZ_ptr: int, m: int, R, d_idf_ptr: int, batch: bool = True):
+        """update() with Z (2 x m scalars) and idf (m int32) already in HBM (raw device pointers)."""
+        R = self._mat22(R)
+        check(self._L.cslam_ekf_update_device(self._h, C.c_void_p(dZ_ptr), C.c_int(m), _vp(R), C.c_void_p(d_idf_ptr),
+                                              C.c_int(1 if batch else 0)))
+
+    def augment(self, Z, R):
+        """Slam::augment(X, P, Z, R) -- EKF.cpp:9-26."""
+        Z = np.asarray(Z, dtype=self.dtype)
+        q = 0 if Z.size == 0 else Z.reshape(2, -1, order="F").shape[1]
+        Zc = self._arr(Z) if q else np.zeros(2, dtype=self.dtype)
+        R = self._mat22(R)
+        check(self._L.cslam_ekf_augment(self._h, _vp(Zc), C.c_int(q), _vp(R)))
+
+    def observe_heading(self, phi, use_heading: bool = False):
+        """Slam::observeHeading(X, P, phi, useHeading) -- EKF.cpp:328-352 (default false, slam.h:788)."""
+        check(self._L.cslam_ekf_observe_heading(self._h, C.c_double(float(phi)), C.c_int(1 if use_heading else 0)))
+
+    # reference-style aliases
+    observeHeading = observe_heading
+
+    # ------------------------------------------------------------------ measurement / introspection
+    def set_profiling(self, mode: int):
+        """0 off, 1 every stage of update(), 2 the downdate (P-GEMM) only."""
+        check(self._L.cslam_ekf_set_profiling(self._h, C.c_int(mode)))
+
+    def stage_times(self):
+        ms = (C.c_double * _capi.N_STAGES)()
+        cnt = (C.c_int * _capi.N_STAGES)()
+        check(self._L.cslam_ekf_get_stage_times(self._h, ms, cnt))
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(_capi.STAGE_NAMES)}
+
+    def debug_last_update(self):
+        n = self.n
+        k = C.c_int(0)
+        check(self._L.cslam_ekf_debug_last_update(self._h, None, None, None, None, None, C.byref(k)))
+        k = k.value
+        out = {
+            "PHT": np.zeros((n, k), self.dtype, order="F"),
+            "S": np.zeros((k, k), self.dtype, order="F"),
+            "G": np.zeros((k, k), self.dtype, order="F"),
+            "W1": np.zeros((n, k), self.dtype, order="F"),
+            "V": np.zeros(k, self.dtype),
+        }
+        if k:
+            check(self._L.cslam_ekf_debug_last_update(self._h, _vp(out["PHT"]), _vp(out["S"]), _vp(out["G"]),
+                                                      _vp(out["W1"]), _vp(out["V"]), C.byref(C.c_int(0))))
+        return out
+
+
+class EngineBackend:
+    """Adapter giving the HIP engine the surface oracle/sim_driver.run_demo() drives."""
+
+    def __init__(self, dtype=np.float32, quirks=Q_REF_EXACT, max_landmarks=64):
+        self.ekf = EKF(max_landmarks, dtype=dtype, quirks=quirks)
+
+    @property
+    def n(self):
+        return self.ekf.n
+
+    def predict(self, v, swa, Q, wb, dt):
+        self.ekf.predict(v, swa, Q, wb, dt)
+
+    def observe_heading(self, phi, use):
+        self.ekf.observe_heading(phi, use)
+
+    def update(self, Z, R, idf, batch):
+        self.ekf.update(Z, R, idf, batch)
+
+    def augment(self, Z, R):
+        self.ekf.augment(Z, R)
+
+    def get_x(self):
+        return self.ekf.get_x()
+
+    def get_p(self):
+        return self.ekf.get_p()

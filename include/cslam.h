@@ -1,0 +1,192 @@
+/*
+ * cslam.h -- C ABI of the MI355X-native EKF-SLAM / FastSLAM-2 engine (libcslam_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of mfkiwl/conan-slam: the entry points below are what
+ * a binding behind the reference's `class Slam` virtuals would call.  Each one cites the reference
+ * interface it replaces (file:line relative to the reference tree).  Plain C types only: opaque handles,
+ * raw pointers, sizes and status codes; no exceptions cross the boundary (the reference swallows its
+ * exceptions and continues, e.g. EKF.cpp:125-128 -- a binding maps a non-zero status to that behaviour).
+ *
+ * Conventions (identical to the reference, which uses Eigen's defaults):
+ *   - matrices are COLUMN-MAJOR; element (r,c) of a matrix with leading dimension ld is a[c*ld + r];
+ *   - state X = [x, y, phi, lm1.x, lm1.y, ...], n = 3 + 2*N;  P is n x n;
+ *   - feature indices `idf` are 1-BASED positions in the state (EKF.cpp:357, PF.cpp:86);
+ *   - Z is 2 x m column-major: Z[2*i] = range, Z[2*i+1] = bearing (rad);
+ *   - "scalar" pointers (const void*) point at elements of the dtype chosen at create time
+ *     (float for CSLAM_F32 -- the reference's own precision -- or double for CSLAM_F64).
+ *
+ * Ownership: the handle owns the authoritative X and P in HBM (P preallocated for max_landmarks,
+ * padded leading dimension).  Host copies are refreshed by get_x / get_state.  Calls on one handle are
+ * stream-ordered and asynchronous unless stated otherwise; a handle is NOT thread-safe; distinct
+ * handles are independent (own stream) and may be driven from distinct host threads.
+ *
+ * There is NO CPU fallback: every entry point fails with CSLAM_ERR_NO_DEVICE / CSLAM_ERR_HIP when no
+ * gfx950 device or kernel image is available.
+ */
+#ifndef CSLAM_H
+#define CSLAM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSLAM_VERSION 100
+
+/* ---- status codes ---- */
+#define CSLAM_OK 0
+#define CSLAM_ERR_BAD_ARG 1    /* null pointer, negative size, idf out of range, wrong dtype ...      */
+#define CSLAM_ERR_CAPACITY 2   /* state would exceed max_landmarks / max_features                     */
+#define CSLAM_ERR_HIP 3        /* a HIP runtime call failed; see cslam_last_error()                   */
+#define CSLAM_ERR_NO_DEVICE 4  /* no usable GPU                                                       */
+#define CSLAM_ERR_ALLOC 5      /* host or device allocation failed                                    */
+/* sticky per-handle factorisation flags (bit-or), read with cslam_ekf_factor_status() */
+#define CSLAM_FACTOR_OK 0
+#define CSLAM_FACTOR_FALLBACK 1 /* LLT of S failed; eigen "square root" taken (slam.h:425-429)        */
+#define CSLAM_FACTOR_ZEROED 2   /* factor or its inverse non-finite -> update was a no-op (slam.h:252-255, 431-434) */
+#define CSLAM_FACTOR_SKIPPED 4  /* async mode: LLT failed and the update was skipped (see set_sync_mode) */
+
+/* ---- precision ---- */
+#define CSLAM_F32 0 /* the reference's precision (Eigen::MatrixXf everywhere)                          */
+#define CSLAM_F64 1
+
+/* ---- quirk flags: which of the reference's behaviours to reproduce ---- */
+#define CSLAM_Q_LOWER_CHOL_GAIN 1 /* slam.h:250-260 with 423: gain built from inv(L), L lower          */
+#define CSLAM_Q_PREDICT_NM4 2     /* EKF.cpp:442-443: cross-covariance stripe n-4 wide                 */
+#define CSLAM_Q_REF_EXACT 3       /* both: bug-compatible with the reference (default for parity)      */
+#define CSLAM_Q_TEXTBOOK 0        /* the algebra the reference meant                                   */
+
+/* ---- profiling stages reported by cslam_ekf_get_stage_times ---- */
+#define CSLAM_STAGE_GATHER 0   /* PHT = P*H^T (sparse gather form of slam.h:243)                       */
+#define CSLAM_STAGE_FACTOR 1   /* S, symmetrise, chol, inverse (slam.h:244-255)                        */
+#define CSLAM_STAGE_GAIN 2     /* W1 = PHT*G, X += W1*(G^T V) (slam.h:257-259)                         */
+#define CSLAM_STAGE_DOWNDATE 3 /* P -= W1*W1^T (slam.h:260) -- the P-GEMM                              */
+#define CSLAM_N_STAGES 4
+
+typedef struct cslam_ekf* cslam_ekf_t;
+
+/* ---- library-level ---- */
+const char* cslam_last_error(void);       /* message of the last failing call on this thread          */
+int cslam_version(void);
+int cslam_device_count(int* count);
+
+/* ================================ EKF-SLAM ================================================== */
+
+/* Replaces: `new EKF(LM, WP)` + the caller-owned `Eigen::VectorXf X; Eigen::MatrixXf P`
+ * (test/main.cpp:89,107-108).  State starts as X = 0_3, P = 0_3x3 as in the reference driver.
+ * device < 0 selects the current HIP device. */
+int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam_ekf_t* out);
+int cslam_ekf_destroy(cslam_ekf_t h);
+
+/* sync_mode = 1 (default): update() waits for its own completion and performs the reference's
+ * eigen-decomposition fallback (slam.h:425-429) on the host when the LLT of S fails, exactly as the
+ * reference would.  sync_mode = 0: fully asynchronous pipeline; a failed LLT makes that update a no-op
+ * and raises CSLAM_FACTOR_SKIPPED (check cslam_ekf_factor_status). */
+int cslam_ekf_set_sync_mode(cslam_ekf_t h, int sync_mode);
+
+/* Upload / download the state.  X: n scalars; P: n x n, leading dimension ldp (>= n), both host memory.
+ * These are what a binding uses where the reference passes X and P by reference into every call. */
+int cslam_ekf_set_state(cslam_ekf_t h, const void* X, int n, const void* P, int ldp);
+int cslam_ekf_get_state(cslam_ekf_t h, void* X, void* P, int ldp); /* synchronises */
+int cslam_ekf_get_x(cslam_ekf_t h, void* X, int capacity);         /* synchronises; writes n scalars */
+int cslam_ekf_get_n(cslam_ekf_t h, int* n);
+int cslam_ekf_trace(cslam_ekf_t h, double* trace);                 /* synchronises */
+int cslam_ekf_synchronize(cslam_ekf_t h);
+int cslam_ekf_factor_status(cslam_ekf_t h, int* flags, int clear); /* synchronises */
+
+/* Replaces Slam::predict(X, P, v, swa, Q, wb, dt)  -- slam.h:841-847, EKF.cpp:406-455.
+ * Q: 2x2 scalars. */
+int cslam_ekf_predict(cslam_ekf_t h, double v, double swa, const void* Q, double wb, double dt);
+
+/* Replaces Slam::update(X, P, Z, R, idf, batch)  -- slam.h:938-943, EKF.cpp:481-496
+ * (batchUpdate EKF.cpp:93-129, singleUpdate EKF.cpp:457-479, observeModel EKF.cpp:354-404,
+ *  choleskyUpdate slam.h:235-266).  Z: 2 x m scalars, R: 2x2 scalars, idf: m ints (1-based), all host
+ * memory, consumed before return.  m = 0 is a no-op, as in the reference. */
+int cslam_ekf_update(cslam_ekf_t h, const void* Z, int m, const void* R, const int* idf, int batch);
+
+/* Same, with Z and idf already resident in device memory (HBM); R stays a host pointer (4 scalars). */
+int cslam_ekf_update_device(cslam_ekf_t h, const void* dZ, int m, const void* R, const int* d_idf, int batch);
+
+/* Replaces Slam::augment(X, P, Z, R)  -- slam.h:190-191, EKF.cpp:9-26 / addOneNewFeature EKF.cpp:28-91.
+ * Z: 2 x q scalars (host). Fails with CSLAM_ERR_CAPACITY beyond max_landmarks. */
+int cslam_ekf_augment(cslam_ekf_t h, const void* Z, int q, const void* R);
+
+/* Replaces Slam::observeHeading(X, P, phi, useHeading)  -- slam.h:788, EKF.cpp:328-352 with
+ * josephUpdate slam.h:700-725 (evaluated in its exact rank-structured O(n^2) form). */
+int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading);
+
+/* Per-stage device times of update() measured with HIP events on the handle's stream.
+ * on = 1 starts recording (events around every stage of every update), on = 0 stops.
+ * get: synchronises, writes the SUM of milliseconds per stage since profiling was switched on and the
+ * number of launches per stage. */
+int cslam_ekf_set_profiling(cslam_ekf_t h, int on);
+int cslam_ekf_get_stage_times(cslam_ekf_t h, double* ms_sum, int* launches);
+
+/* Introspection for tests: copy the update intermediates of the LAST batch update to the host.
+ * PHT and W1 are n x k (leading dimension n on output), S and G are k x k, V and t have k entries.
+ * Any pointer may be NULL. Synchronises. */
+int cslam_ekf_debug_last_update(cslam_ekf_t h, void* PHT, void* S, void* G, void* W1, void* V, int* k);
+
+/* ================================ FastSLAM-2 particle set ==================================== */
+typedef struct cslam_pf* cslam_pf_t;
+
+/* Replaces PF::initializeParticles(numParticles)  -- slam.h:688, PF.cpp:319-341, for the
+ * n_particles this process owns (one shard of the global set; see INTEGRATION.md for the sharding).
+ * Layout is structure-of-arrays in HBM. */
+int cslam_pf_create(int n_particles, int max_features, int dtype, int device, int quirks, cslam_pf_t* out);
+int cslam_pf_destroy(cslam_pf_t h);
+int cslam_pf_synchronize(cslam_pf_t h);
+int cslam_pf_get_counts(cslam_pf_t h, int* n_particles, int* n_features);
+
+/* set every particle's weight to w0 (PF.cpp:327 uses 1/N of the GLOBAL particle count) */
+int cslam_pf_set_uniform_weight(cslam_pf_t h, double w0);
+
+/* Replaces PF::predict(particle, v, swa, Q, wb, dt) for every owned particle -- slam.h:858-863,
+ * PF.cpp:419-471. */
+int cslam_pf_predict(cslam_pf_t h, double v, double swa, const void* Q, double wb, double dt);
+
+/* Replaces PF::observeHeading(particle, phi, use) for every owned particle -- PF.cpp:382-417. */
+int cslam_pf_observe_heading(cslam_pf_t h, double phi, int use_heading);
+
+/* Replaces PF::sampleProposal(particle, Z, idf, R) for every owned particle -- slam.h:881-884,
+ * PF.cpp:502-544 (computeJacobians PF.cpp:70-135, likelihood 343-359, gaussEvaluate 279-317).
+ * normals: 3 x n_particles scalars (host), the N(0,1) draws slam.h:753-764 would make. */
+int cslam_pf_sample_proposal(cslam_pf_t h, const void* Z, int m, const int* idf, const void* R,
+                             const void* normals);
+
+/* Replaces PF::featureUpdate(particle, Z, idf, R) for every owned particle -- slam.h:549-552,
+ * PF.cpp:222-277. */
+int cslam_pf_feature_update(cslam_pf_t h, const void* Z, int m, const int* idf, const void* R);
+
+/* Replaces PF::addOneNewFeature(particle, Z, R) for every owned particle -- slam.h:134, PF.cpp:9-60. */
+int cslam_pf_add_features(cslam_pf_t h, const void* Z, int q, const void* R);
+
+/* ---- the resample step (PF.cpp:473-500, 546-577), split so that a multi-GPU driver can put its
+ *      collectives between the pieces; see INTEGRATION.md ---- */
+/* local partial sums: sums[0] = sum w, sums[1] = sum w^2 (doubles, host). Synchronises. */
+int cslam_pf_weight_sums(cslam_pf_t h, double* sums);
+/* w *= scale (the 1/ws of PF.cpp:482-487 with ws the GLOBAL sum) */
+int cslam_pf_scale_weights(cslam_pf_t h, double scale);
+/* device pointer to the owned weights (n_particles scalars) for an all-gather */
+int cslam_pf_weights_device_ptr(cslam_pf_t h, void** dptr);
+int cslam_pf_get_weights(cslam_pf_t h, void* w_host); /* synchronises */
+int cslam_pf_set_weights(cslam_pf_t h, const void* w_host);
+/* size in bytes of one packed particle record (w, Xv, Pv, XF, PF for max_features) */
+int cslam_pf_record_bytes(cslam_pf_t h, long long* bytes);
+/* pack the particles src_idx[0..count) (local 0-based indices, host array) into the device buffer
+ * d_records (count * record_bytes), e.g. a send buffer of the all-to-all-v */
+int cslam_pf_pack(cslam_pf_t h, const int* src_idx, int count, void* d_records);
+/* overwrite local slots dst_idx[0..count) from packed records in device memory */
+int cslam_pf_unpack(cslam_pf_t h, const int* dst_idx, int count, const void* d_records);
+/* purely local resample: slot i <- copy of local particle keep[i] (0-based), all weights = w_new */
+int cslam_pf_gather_local(cslam_pf_t h, const int* keep, double w_new);
+/* download one particle (host buffers; any may be NULL): w (1), Xv (3), Pv (9), XF (2*nf), PF (4*nf) */
+int cslam_pf_get_particle(cslam_pf_t h, int index, void* w, void* Xv, void* Pv, void* XF, void* PF);
+/* upload one particle with nf features (nf must equal the current feature count, or set it when the
+ * store is empty of features) */
+int cslam_pf_set_particle(cslam_pf_t h, int index, const void* w, const void* Xv, const void* Pv,
+                          const void* XF, const void* PF, int nf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSLAM_H */

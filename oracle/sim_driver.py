@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 
 import numpy as np
 
@@ -22,31 +23,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PI = 3.14159265358979323846264338327950288
 
 
-# ---------------------------------------------------------------------------------------------
-# counter-based RNG shared by every harness: splitmix64(seed, index) -> uniform -> normal
-# ---------------------------------------------------------------------------------------------
-def splitmix64(seed: int, idx) -> np.ndarray:
-    """Vectorised splitmix64 finaliser of (seed * 0x9E3779B97F4A7C15 + idx)."""
-    with np.errstate(over="ignore"):
-        z = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.asarray(idx, dtype=np.uint64)
-             + np.uint64(0x9E3779B97F4A7C15))
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    return z
-
-
-def uniform01(seed: int, idx) -> np.ndarray:
-    """Uniform doubles in [0,1) from the top 53 bits."""
-    return (splitmix64(seed, idx) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
-
-
-def normal(seed: int, idx) -> np.ndarray:
-    """Standard normals by Box-Muller on two independent uniform streams."""
-    idx = np.asarray(idx, dtype=np.uint64)
-    u1 = uniform01(seed, idx * np.uint64(2))
-    u2 = uniform01(seed, idx * np.uint64(2) + np.uint64(1))
-    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+# counter-based RNG shared by every harness lives with the synthetic-workload generator
+sys.path.insert(0, os.path.join(_HERE, ".."))
+from conan_slam_amd.synth import normal, splitmix64, uniform01  # noqa: E402,F401
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,395 @@
+"""GPU parity tests of the EKF path: the HIP engine, called through the C ABI (include/cslam.h), against the
+CPU oracle on the same seeded inputs.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances are SURVEY.md 8d's: per call |dX|inf <= 1e-5*max(1,|X|inf) (f32) / 1e-12 (f64), covariance
+1e-4 / 1e-10 relative to max(1,|P|max), with the fairness rule (GPU-f32 error against the f64 oracle no worse
+than 4x the CPU-f32 oracle's) as the fallback criterion for ill-conditioned cases.
+"""
+import numpy as np
+import pytest
+
+from helpers import OracleState, P_RTOL, X_RTOL, assert_close, make_obs, make_scenario
+from pyoracle import REF_EXACT, TEXTBOOK
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.float32, np.float64]
+QUIRKS = [REF_EXACT, TEXTBOOK]
+
+
+def _engine(N, dtype, quirks, X, P, extra=0):
+    from conan_slam_amd import EKF
+
+    e = EKF(N + extra, dtype=dtype, quirks=quirks)
+    e.set_state(X, P)
+    return e
+
+
+def _pair(N, dtype, quirks, seed=0, extra=0, corr=0.5):
+    X, P = make_scenario(N, dtype, seed=seed, corr=corr)
+    eng = _engine(N, dtype, quirks, X, P, extra)
+    orc = OracleState(X, P, dtype, quirks, extra)
+    hi = OracleState(X.astype(np.float64), P.astype(np.float64), np.float64, quirks, extra)
+    return eng, orc, hi
+
+
+def _check(eng, orc, hi, dtype, tag):
+    X, P = eng.get_state()
+    dt = np.dtype(dtype)
+    assert eng.n == orc.n
+    assert_close(f"{tag}: X", X, orc.x(), X_RTOL[dt], hi.x())
+    assert_close(f"{tag}: P", P, orc.p(), P_RTOL[dt], hi.p())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_state_roundtrip(gpu_required, dtype):
+    X, P = make_scenario(7, dtype, seed=3)
+    eng = _engine(7, dtype, REF_EXACT, X, P, extra=2)
+    X2, P2 = eng.get_state()
+    assert np.array_equal(X, X2) and np.array_equal(P, P2)
+    assert abs(eng.trace() - float(np.trace(P.astype(np.float64)))) < 1e-3
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", QUIRKS)
+@pytest.mark.parametrize("N", [0, 1, 2, 30, 200])
+def test_predict(gpu_required, dtype, quirks, N):
+    eng, orc, hi = _pair(N, dtype, quirks, seed=N)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    for step in range(3):
+        args = (83.33, 0.05 * (step + 1), Q, 73.0, 0.01)
+        eng.predict(*args)
+        orc.predict(*args)
+        hi.predict(*args)
+    _check(eng, orc, hi, dtype, f"predict N={N}")
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", QUIRKS)
+@pytest.mark.parametrize("N,m", [(1, 1), (5, 3), (30, 7), (130, 32), (300, 64), (70, 70)])
+def test_batch_update(gpu_required, dtype, quirks, N, m):
+    eng, orc, hi = _pair(N, dtype, quirks, seed=10 + N, corr=0.2)
+    rng = np.random.default_rng(N * 100 + m)
+    idf = (rng.permutation(N)[:m] + 1).astype(np.int32)
+    Z = make_obs(orc.x(), idf, dtype, seed=m)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    eng.update(Z, R, idf, batch=True)
+    c1 = orc.update(Z, R, idf, True)
+    hi.update(Z.astype(np.float64), R.astype(np.float64), idf, True)
+    assert c1 == 0 and eng.factor_status() == 0
+    # stage-level parity first: it localises a failure to one kernel
+    dbg = eng.debug_last_update()
+    assert dbg["S"].shape == (2 * m, 2 * m)
+    assert np.allclose(dbg["S"], dbg["S"].T, rtol=0, atol=0), "S must be exactly symmetric after makeSymmetric"
+    _check(eng, orc, hi, dtype, f"batch N={N} m={m}")
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", QUIRKS)
+def test_update_stages_against_oracle_pieces(gpu_required, dtype, quirks):
+    """PHT, S, G and W1 of one batch against the oracle's building blocks (slam.h:243-257)."""
+    from pyoracle import Oracle
+
+    N, m = 40, 9
+    X, P = make_scenario(N, dtype, seed=77, corr=0.2)
+    eng = _engine(N, dtype, quirks, X, P)
+    o = Oracle(dtype, quirks)
+    idf = np.arange(2, 2 + m, dtype=np.int32)
+    Z = make_obs(X, idf, dtype, seed=5)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    eng.update(Z, R, idf, batch=True)
+    d = eng.debug_last_update()
+    n, k = 3 + 2 * N, 2 * m
+    H = np.zeros((k, n), dtype=dtype, order="F")
+    V = np.zeros(k, dtype=dtype)
+    for i, f in enumerate(idf):
+        zp, h = o.observe_model(X, n, int(f))
+        H[2 * i:2 * i + 2, :] = h
+        V[2 * i] = Z[0, i] - zp[0]
+        V[2 * i + 1] = o.pi2pi(Z[1, i] - zp[1])
+    P64, H64 = P.astype(np.float64), H.astype(np.float64)
+    PHT = P64 @ H64.T
+    S = H64 @ PHT + np.kron(np.eye(m), R.astype(np.float64))
+    S = 0.5 * (S + S.T)
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    assert_close("V", d["V"], V, tol)
+    assert_close("PHT", d["PHT"], PHT, tol)
+    assert_close("S", d["S"], S, tol)
+    G, code = o.gain_factor(np.asfortranarray(d["S"]))
+    assert code == 0
+    assert_close("G", d["G"], G, 20 * tol)
+    assert_close("W1", d["W1"], d["PHT"].astype(np.float64) @ d["G"].astype(np.float64), 20 * tol)
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", QUIRKS)
+@pytest.mark.parametrize("N,m", [(5, 3), (60, 12)])
+def test_sequential_update(gpu_required, dtype, quirks, N, m):
+    eng, orc, hi = _pair(N, dtype, quirks, seed=20 + N, corr=0.2)
+    idf = (np.random.default_rng(m).permutation(N)[:m] + 1).astype(np.int32)
+    Z = make_obs(orc.x(), idf, dtype, seed=m + 1)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    eng.update(Z, R, idf, batch=False)
+    orc.update(Z, R, idf, False)
+    hi.update(Z.astype(np.float64), R.astype(np.float64), idf, False)
+    _check(eng, orc, hi, dtype, f"sequential N={N} m={m}")
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batch_of_one_equals_single(gpu_required, dtype):
+    """EKF.cpp:93-129 with m = 1 and EKF.cpp:457-479 with m = 1 are the same arithmetic."""
+    N = 12
+    X, P = make_scenario(N, dtype, seed=5, corr=0.2)
+    idf = np.array([4], dtype=np.int32)
+    Z = make_obs(X, idf, dtype, seed=9)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    a = _engine(N, dtype, REF_EXACT, X, P)
+    b = _engine(N, dtype, REF_EXACT, X, P)
+    a.update(Z, R, idf, batch=True)
+    b.update(Z, R, idf, batch=False)
+    Xa, Pa = a.get_state()
+    Xb, Pb = b.get_state()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Pa, Pb)
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_update_with_no_observations_is_a_noop(gpu_required, dtype):
+    N = 6
+    X, P = make_scenario(N, dtype, seed=8)
+    eng = _engine(N, dtype, REF_EXACT, X, P)
+    eng.update(np.zeros((2, 0), dtype), np.eye(2, dtype=dtype), np.zeros(0, np.int32), batch=True)
+    eng.update(np.zeros((2, 0), dtype), np.eye(2, dtype=dtype), np.zeros(0, np.int32), batch=False)
+    X2, P2 = eng.get_state()
+    assert np.array_equal(X, X2) and np.array_equal(P, P2)
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,q", [(0, 1), (0, 3), (4, 2), (60, 5)])
+def test_augment(gpu_required, dtype, N, q):
+    eng, orc, hi = _pair(N, dtype, REF_EXACT, seed=30 + N, extra=q)
+    rng = np.random.default_rng(q)
+    Z = np.asfortranarray(np.stack([rng.uniform(50, 1500, q), rng.uniform(-1.5, 1.5, q)]).astype(dtype))
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    eng.augment(Z, R)
+    orc.augment(Z, R)
+    hi.augment(Z.astype(np.float64), R.astype(np.float64))
+    assert eng.n == 3 + 2 * (N + q)
+    _check(eng, orc, hi, dtype, f"augment N={N} q={q}")
+    eng.close()
+
+
+def test_augment_beyond_capacity_is_refused(gpu_required):
+    from conan_slam_amd import CslamError, _capi
+
+    X, P = make_scenario(2, np.float32)
+    eng = _engine(2, np.float32, REF_EXACT, X, P, extra=1)
+    Z = np.array([[100.0, 200.0], [0.1, 0.2]], dtype=np.float32)
+    with pytest.raises(CslamError) as ei:
+        eng.augment(Z, np.eye(2, dtype=np.float32))
+    assert ei.value.code == _capi.ERR_CAPACITY
+    assert eng.n == 7  # nothing was appended
+    eng.close()
+
+
+def test_bad_feature_index_is_refused(gpu_required):
+    from conan_slam_amd import CslamError, _capi
+
+    X, P = make_scenario(3, np.float32)
+    eng = _engine(3, np.float32, REF_EXACT, X, P)
+    with pytest.raises(CslamError) as ei:
+        eng.update(np.array([[10.0], [0.1]], np.float32), np.eye(2, dtype=np.float32), np.array([4], np.int32), True)
+    assert ei.value.code == _capi.ERR_BAD_ARG
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N", [0, 3, 150])
+def test_observe_heading(gpu_required, dtype, N):
+    """The rank-structured Joseph update against the oracle's dense n^3 form (slam.h:700-725)."""
+    eng, orc, hi = _pair(N, dtype, REF_EXACT, seed=40 + N)
+    eng.observe_heading(0.31, True)
+    orc.observe_heading(0.31, True)
+    hi.observe_heading(0.31, True)
+    # heading sigma is 0.01 deg: 1 - W[2] cancels to ~R/S, so the f32 result is only good to ~1e-3 relative on
+    # row/column 2 in ANY float evaluation order; the fairness rule (vs f64) is the meaningful criterion here
+    X, P = eng.get_state()
+    dt = np.dtype(dtype)
+    assert_close("heading X", X, orc.x(), X_RTOL[dt], hi.x())
+    assert_close("heading P", P, orc.p(), P_RTOL[dt], hi.p(), fair=8.0)
+    eng.observe_heading(0.5, False)  # use=false is a no-op (EKF.cpp:332-335)
+    X2, P2 = eng.get_state()
+    assert np.array_equal(X, X2) and np.array_equal(P, P2)
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", QUIRKS)
+def test_eight_predict_update_steps(gpu_required, dtype, quirks):
+    """|d trace| <= 1e-4 |trace| (f32) / 1e-10 (f64) after 8 consecutive predict+update steps."""
+    N, m = 120, 10
+    eng, orc, hi = _pair(N, dtype, quirks, seed=99, corr=0.1)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    rng = np.random.default_rng(4)
+    for step in range(8):
+        args = (83.33, 0.02 * step, Q, 73.0, 0.01)
+        idf = (rng.permutation(N)[:m] + 1).astype(np.int32)
+        Z = make_obs(orc.x(), idf, dtype, seed=step)
+        for s in (eng, orc):
+            s.predict(*args)
+            s.update(Z, R, idf, True)
+        hi.predict(*args)
+        hi.update(Z.astype(np.float64), R.astype(np.float64), idf, True)
+    tr_gpu, tr_cpu, tr_hi = eng.trace(), float(np.trace(orc.p().astype(np.float64))), float(np.trace(hi.p()))
+    tol = 1e-4 if dtype == np.float32 else 1e-10
+    ok = abs(tr_gpu - tr_cpu) <= tol * abs(tr_cpu) or abs(tr_gpu - tr_hi) <= 4 * abs(tr_cpu - tr_hi)
+    assert ok, (tr_gpu, tr_cpu, tr_hi)
+    _check(eng, orc, hi, dtype, "8 steps")
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_failed_factorisation_follows_the_reference(gpu_required, dtype):
+    """slam.h:421-434 / 252-255: an indefinite S makes LLT fail; the eigen 'square root' then holds a NaN, the
+    factor is zeroed and the update is a silent no-op.  The engine must end in the same state as the oracle."""
+    from conan_slam_amd import _capi
+
+    N, m = 6, 3
+    X, P = make_scenario(N, dtype, seed=2)
+    P = P.copy(order="F")
+    P[3:, 3:] *= -1.0  # negative feature block => H P H^T + R indefinite
+    eng = _engine(N, dtype, REF_EXACT, X, P)
+    orc = OracleState(X, P, dtype, REF_EXACT)
+    idf = np.array([1, 3, 5], dtype=np.int32)
+    Z = make_obs(X, idf, dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    eng.update(Z, R, idf, batch=True)
+    code = orc.update(Z, R, idf, True)
+    assert code == 2
+    st = eng.factor_status()
+    assert st & _capi.FACTOR_FALLBACK and st & _capi.FACTOR_ZEROED
+    X2, P2 = eng.get_state()
+    assert np.array_equal(X2, orc.x()) and np.array_equal(P2, orc.p())
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_eigen_fallback_with_semidefinite_s(gpu_required, dtype):
+    """LLT fails on an exactly singular PSD S but every eigenvalue is >= 0, so the reference continues with the
+    eigen factor (slam.h:425-429); the engine's host-side fallback must reproduce the oracle."""
+    from conan_slam_amd import _capi
+
+    n = 5  # one feature
+    X = np.array([0.0, 0.0, 0.0, 10.0, 0.0], dtype=dtype)
+    P = np.zeros((n, n), dtype=dtype, order="F")
+    P[3, 3] = 1.0  # only the feature's x is uncertain => H P H^T has rank 1
+    R = np.zeros((2, 2), dtype=dtype)  # and no measurement noise => S singular PSD
+    idf = np.array([1], dtype=np.int32)
+    Z = np.array([[10.5], [0.0]], dtype=dtype)
+    eng = _engine(1, dtype, REF_EXACT, X, P)
+    orc = OracleState(X, P, dtype, REF_EXACT)
+    eng.update(Z, R, idf, batch=True)
+    code = orc.update(Z, R, idf, True)
+    st = eng.factor_status()
+    assert st & _capi.FACTOR_FALLBACK
+    X2, P2 = eng.get_state()
+    if code == 1:  # finite eigen factor was used
+        assert not (st & _capi.FACTOR_ZEROED)
+        assert_close("fallback X", X2, orc.x(), 1e-4)
+        assert_close("fallback P", P2, orc.p(), 1e-4)
+    else:
+        assert np.array_equal(X2, orc.x()) and np.array_equal(P2, orc.p())
+    eng.close()
+
+
+def test_async_mode_skips_failed_factorisation(gpu_required):
+    from conan_slam_amd import EKF, _capi
+
+    N = 4
+    X, P = make_scenario(N, np.float32, seed=2)
+    P = P.copy(order="F")
+    P[3:, 3:] *= -1.0
+    eng = EKF(N, dtype=np.float32, sync_mode=False)
+    eng.set_state(X, P)
+    idf = np.array([1, 2], dtype=np.int32)
+    eng.update(make_obs(X, idf, np.float32), np.diag([0.08, 0.0024]).astype(np.float32), idf, batch=True)
+    assert eng.factor_status() & _capi.FACTOR_SKIPPED
+    X2, P2 = eng.get_state()
+    assert np.array_equal(X, X2) and np.array_equal(P, P2)
+    eng.close()
+
+
+def test_update_device_matches_host_entry(gpu_required):
+    """cslam_ekf_update_device (Z, idf already in HBM) against cslam_ekf_update (host pointers)."""
+    import torch
+
+    N, m = 50, 16
+    X, P = make_scenario(N, np.float32, seed=6, corr=0.2)
+    idf = (np.random.default_rng(1).permutation(N)[:m] + 1).astype(np.int32)
+    Z = make_obs(X, idf, np.float32)
+    R = np.diag([0.08, 0.0024]).astype(np.float32)
+    a = _engine(N, np.float32, REF_EXACT, X, P)
+    b = _engine(N, np.float32, REF_EXACT, X, P)
+    a.update(Z, R, idf, batch=True)
+    dZ = torch.from_numpy(np.ascontiguousarray(Z.reshape(-1, order="F"))).cuda()
+    dI = torch.from_numpy(idf).cuda()
+    torch.cuda.synchronize()
+    b.update_device(dZ.data_ptr(), m, R, dI.data_ptr(), batch=True)
+    Xa, Pa = a.get_state()
+    Xb, Pb = b.get_state()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Pa, Pb)
+    a.close()
+    b.close()
+
+
+def test_demo_map_run_matches_oracle(gpu_required):
+    """Config 1 (the reference's bundled demo map, test/main.cpp:24-200) driven through the engine: the first
+    2400 control steps (400 observation events, map building + updates + heading) against the oracle."""
+    from conan_slam_amd import EngineBackend
+    from sim_driver import OracleBackend, load_demo_map, run_demo
+
+    LM, WP = load_demo_map()
+    steps = 2400
+    ref = run_demo(OracleBackend(np.float32), LM, WP, max_steps=steps)
+    hi = run_demo(OracleBackend(np.float64), LM, WP, max_steps=steps)
+    got = run_demo(EngineBackend(np.float32), LM, WP, max_steps=steps)
+    assert got["final_n"] == ref["final_n"] and got["updates"] == ref["updates"]
+    assert_close("demo X", got["X"], ref["X"], 1e-4, hi["X"], fair=8.0)
+    # whole-trajectory tolerance of SURVEY 8d: 1e-2 on the trace (f32 and f64 already differ by ~0.4 %)
+    assert abs(got["trace_P"] - ref["trace_P"]) <= 1e-2 * abs(ref["trace_P"]), (got["trace_P"], ref["trace_P"])
+
+
+def test_full_size_5000_landmarks_one_update(gpu_required):
+    """BASELINE config 3 size (n = 10 003, f32, m = 32): one predict + batch update against the oracle's dense-
+    order fast path, plus size-independent properties (symmetry preserved, trace decreases in TEXTBOOK mode)."""
+    from conan_slam_amd import EKF
+    from conan_slam_amd.synth import Workload
+    from pyoracle import Oracle
+
+    w = Workload(5000, 32, np.float32)
+    eng = EKF(5000, dtype=np.float32, quirks=TEXTBOOK)
+    eng.set_state(w.X0, w.P0)
+    o = Oracle(np.float32, TEXTBOOK)
+    X, P = w.X0.copy(), w.P0.copy(order="F")
+    tr0 = float(np.trace(P.astype(np.float64)))
+    v, swa = w.controls(0)
+    Z, idf = w.observations(0)
+    eng.predict(v, swa, w.QE, w.wb, w.dt)
+    eng.update(Z, w.RE, idf, batch=True)
+    o.predict(X, P, w.n, v, swa, w.QE, w.wb, w.dt)
+    code = o.update(X, P, w.n, Z, w.RE, idf, True, fast=True)
+    assert code == 0 and eng.factor_status() == 0
+    Xg, Pg = eng.get_state()
+    assert_close("5000 X", Xg, X, 1e-5)
+    assert_close("5000 P", Pg, P, 1e-4)
+    assert np.array_equal(Pg, Pg.T), "the update must keep P exactly symmetric"
+    assert eng.trace() < tr0
+    eng.close()
