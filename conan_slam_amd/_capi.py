@@ -35,6 +35,31 @@ def declared_symbols(header_path: str = HEADER_PATH):
 
 
 _lib = None
+hip_runtime_path = None  # which libamdhip64 the engine ended up bound to (diagnostics)
+
+
+def _preload_shared_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (SONAME libamdhip64.so.7, the same SONAME libcslam_hip.so is linked against); if the engine bound the
+    system copy under /opt/rocm and torch later loaded its own, the second runtime would see no GPU.  So when
+    torch is installed its bundled runtime is loaded first (without importing torch) and the engine's
+    DT_NEEDED resolves to it by SONAME.  CSLAM_HIP_RUNTIME=system keeps the /opt/rocm runtime (for processes
+    that never touch torch's GPU side)."""
+    global hip_runtime_path
+    if os.environ.get("CSLAM_HIP_RUNTIME", "torch") == "system":
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            hip_runtime_path = cand
+    except Exception:
+        pass  # fall back to the system runtime
 
 
 def lib() -> C.CDLL:
@@ -45,6 +70,7 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -m conan_slam_amd.build` (hipcc, gfx950). "
                 "There is no CPU fallback for the engine.")
+        _preload_shared_hip_runtime()
         _lib = C.CDLL(LIB_PATH)
         _lib.cslam_last_error.restype = C.c_char_p
     return _lib

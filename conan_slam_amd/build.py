@@ -16,7 +16,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcslam_hip.so")
 
 SOURCES = ["cslam_ekf.hip", "cslam_pf.hip"]
-HEADERS = ["cslam_common.hpp", "ekf_kernels.hpp", "pf_kernels.hpp", "host_linalg.hpp", "../../include/cslam.h"]
+HEADERS = ["cslam_common.hpp", "ekf_kernels.hpp", "pf_kernels.hpp", "host_linalg.hpp", "device_math.hpp", "../../include/cslam.h"]
 ARCH = "gfx950"
 
 

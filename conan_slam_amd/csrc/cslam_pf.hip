@@ -1,0 +1,753 @@
+// cslam_pf.hip -- host side of the FastSLAM-2 particle store behind the C ABI of include/cslam.h.
+//
+// One handle owns np particles (one shard of the global particle set) in structure-of-arrays form in HBM
+// and launches one lane per particle (or per particle x observation).  The only step of the reference that
+// couples particles -- resampleParticles, PF.cpp:473-500 -- is exposed in pieces (weight sums, scaling,
+// pack / unpack of particle records, local gather) so that a multi-GPU driver can put its collectives
+// between them (conan_slam_amd/pf.py does that with torch.distributed over RCCL).
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "cslam_common.hpp"
+#include "pf_kernels.hpp"
+
+using namespace cslam;
+
+namespace
+{
+
+struct PfBase
+{
+    virtual ~PfBase() {}
+    int         dtype  = CSLAM_F32;
+    int         device = 0;
+    int         quirks = CSLAM_Q_REF_EXACT;
+    int         np     = 0;
+    int         nfcap  = 0;
+    int         nf     = 0;
+    hipStream_t stream = nullptr;
+
+    virtual int init()                                                                       = 0;
+    virtual int set_uniform_weight(double w0)                                                 = 0;
+    virtual int predict(double v, double swa, const void* Q, double wb, double dt)            = 0;
+    virtual int observe_heading(double phi, int use)                                          = 0;
+    virtual int sample_proposal(const void* Z, int m, const int* idf, const void* R, const void* normals) = 0;
+    virtual int feature_update(const void* Z, int m, const int* idf, const void* R)           = 0;
+    virtual int add_features(const void* Z, int q, const void* R)                             = 0;
+    virtual int weight_sums(double* sums)                                                     = 0;
+    virtual int scale_weights(double scale)                                                   = 0;
+    virtual int weights_ptr(void** p)                                                         = 0;
+    virtual int get_weights(void* w)                                                          = 0;
+    virtual int set_weights(const void* w)                                                    = 0;
+    virtual int record_bytes(long long* b)                                                    = 0;
+    virtual int pack(const int* idx, int count, void* drec)                                   = 0;
+    virtual int unpack(const int* idx, int count, const void* drec)                           = 0;
+    virtual int gather_local(const int* keep, double w_new)                                   = 0;
+    virtual int get_particle(int i, void* w, void* Xv, void* Pv, void* XF, void* PF)          = 0;
+    virtual int set_particle(int i, const void* w, const void* Xv, const void* Pv, const void* XF, const void* PF,
+                             int nf)                                                          = 0;
+};
+
+template <typename T>
+struct Pf : PfBase
+{
+    T*      dW   = nullptr;
+    T*      dXv  = nullptr;
+    T*      dPv  = nullptr;
+    T*      dXF  = nullptr;
+    T*      dPF  = nullptr;
+    T*      dObs = nullptr; // staging: Z (2*mcap) | normals (3*np)
+    int*    dIdx = nullptr; // staging: idf / index lists (max(mcap, np))
+    double* dSums = nullptr;
+    T*      dRec = nullptr; // scratch for gather_local
+    int     mcap = 0;
+
+    ~Pf() override
+    {
+        if (stream)
+        {
+            (void)hipStreamSynchronize(stream);
+        }
+        (void)hipFree(dW);
+        (void)hipFree(dXv);
+        (void)hipFree(dPv);
+        (void)hipFree(dXF);
+        (void)hipFree(dPF);
+        (void)hipFree(dObs);
+        (void)hipFree(dIdx);
+        (void)hipFree(dSums);
+        (void)hipFree(dRec);
+        if (stream)
+        {
+            (void)hipStreamDestroy(stream);
+        }
+    }
+
+    int use_device()
+    {
+        CSLAM_HIP_TRY(hipSetDevice(device));
+        return CSLAM_OK;
+    }
+
+    PfStore<T> store() const
+    {
+        PfStore<T> s;
+        s.w  = dW;
+        s.xv = dXv;
+        s.pv = dPv;
+        s.xf = dXF;
+        s.pf = dPF;
+        s.np = np;
+        s.nf = nf;
+        return s;
+    }
+
+    int ensure_m(int m)
+    {
+        if (m <= mcap)
+        {
+            return CSLAM_OK;
+        }
+        int newm = std::max(m, std::max(64, 2 * mcap));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(dObs);
+        (void)hipFree(dIdx);
+        dObs = nullptr;
+        dIdx = nullptr;
+        CSLAM_HIP_TRY(hipMalloc(&dObs, ((size_t)2 * newm + (size_t)3 * np) * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dIdx, (size_t)std::max(newm, np) * sizeof(int)));
+        mcap = newm;
+        return CSLAM_OK;
+    }
+
+    int init() override
+    {
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        size_t n1 = (size_t)np;
+        size_t cf = (size_t)std::max(nfcap, 1);
+        CSLAM_HIP_TRY(hipMalloc(&dW, n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dXv, 3 * n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dPv, 9 * n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dXF, 2 * cf * n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dPF, 4 * cf * n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dSums, 2 * sizeof(double)));
+        CSLAM_HIP_TRY(hipMalloc(&dRec, n1 * (13 + 6 * cf) * sizeof(T)));
+        // PF.cpp:319-341: X = 0, P = 0, empty map; w = 1/np until the driver sets the global value
+        CSLAM_HIP_TRY(hipMemsetAsync(dXv, 0, 3 * n1 * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPv, 0, 9 * n1 * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dXF, 0, 2 * cf * n1 * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPF, 0, 4 * cf * n1 * sizeof(T), stream));
+        rc = ensure_m(64);
+        if (rc)
+        {
+            return rc;
+        }
+        rc = set_uniform_weight(1.0 / (double)np);
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    int set_uniform_weight(double w0) override
+    {
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        hipLaunchKernelGGL(pf_scale_weights_kernel<T>, dim3((np + 255) / 256), dim3(256), 0, stream, dW, np, (T)w0, 1);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    int predict(double v, double swa, const void* Qv, double wb, double dt) override
+    {
+        if (!Qv)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_predict: Q is null");
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const T* Q = static_cast<const T*>(Qv);
+        hipLaunchKernelGGL(pf_predict_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), (T)v, (T)swa, Q[0],
+                           Q[1], Q[2], Q[3], (T)wb, (T)dt);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    int observe_heading(double phi, int use) override
+    {
+        if (!use)
+        {
+            return CSLAM_OK;
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        T sigma = (T)(((double)0.01f * kPi) / 180.0); // PF.cpp:391
+        hipLaunchKernelGGL(pf_heading_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), (T)phi,
+                           sigma * sigma);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    int check_idf(const int* idf, int m, const char* who)
+    {
+        for (int i = 0; i < m; i++)
+        {
+            if (idf[i] < 1 || idf[i] > nf)
+            {
+                return fail(CSLAM_ERR_BAD_ARG, "%s: idf[%d]=%d outside 1..%d", who, i, idf[i], nf);
+            }
+        }
+        return CSLAM_OK;
+    }
+
+    // stage Z (2*m) and idf (m) of one call; inputs are consumed before return
+    int stage(const void* Z, int m, const int* idf)
+    {
+        int rc = ensure_m(m);
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(dObs, Z, (size_t)2 * m * sizeof(T), hipMemcpyHostToDevice, stream));
+        if (idf)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(dIdx, idf, (size_t)m * sizeof(int), hipMemcpyHostToDevice, stream));
+        }
+        return CSLAM_OK;
+    }
+
+    int sample_proposal(const void* Z, int m, const int* idf, const void* Rv, const void* normals) override
+    {
+        if (m < 0 || !Rv || !normals || (m > 0 && (!Z || !idf)))
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_sample_proposal: bad arguments");
+        }
+        int rc = use_device();
+        if (rc || (rc = check_idf(idf, m, "pf_sample_proposal")) || (rc = stage(Z, m, idf)))
+        {
+            return rc;
+        }
+        T* dN = dObs + (size_t)2 * mcap;
+        CSLAM_HIP_TRY(hipMemcpyAsync(dN, normals, (size_t)3 * np * sizeof(T), hipMemcpyHostToDevice, stream));
+        const T* R = static_cast<const T*>(Rv);
+        hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdx, m,
+                           R[0], R[1], R[2], R[3], dN);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // pageable host inputs were staged asynchronously
+        return CSLAM_OK;
+    }
+
+    int feature_update(const void* Z, int m, const int* idf, const void* Rv) override
+    {
+        if (m < 0 || !Rv || (m > 0 && (!Z || !idf)))
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_feature_update: bad arguments");
+        }
+        if (m == 0)
+        {
+            return CSLAM_OK;
+        }
+        int rc = use_device();
+        if (rc || (rc = check_idf(idf, m, "pf_feature_update")) || (rc = stage(Z, m, idf)))
+        {
+            return rc;
+        }
+        const T* R = static_cast<const T*>(Rv);
+        hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), dObs, dIdx,
+                           m, R[0], R[1], R[2], R[3], (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    int add_features(const void* Z, int q, const void* Rv) override
+    {
+        if (q < 0 || !Rv || (q > 0 && !Z))
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_add_features: bad arguments");
+        }
+        if (q == 0)
+        {
+            return CSLAM_OK;
+        }
+        if (nf + q > nfcap)
+        {
+            return fail(CSLAM_ERR_CAPACITY, "pf_add_features: %d features would exceed max_features=%d", nf + q, nfcap);
+        }
+        int rc = use_device();
+        if (rc || (rc = stage(Z, q, nullptr)))
+        {
+            return rc;
+        }
+        const T* R = static_cast<const T*>(Rv);
+        hipLaunchKernelGGL(pf_add_features_kernel<T>, dim3((np + 63) / 64, q), dim3(64), 0, stream, store(), dObs, q, R[0],
+                           R[1], R[2], R[3]);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        nf += q;
+        return CSLAM_OK;
+    }
+
+    int weight_sums(double* sums) override
+    {
+        if (!sums)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_weight_sums: null");
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        hipLaunchKernelGGL(pf_weight_sums_kernel<T>, dim3(1), dim3(256), 0, stream, dW, np, dSums);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipMemcpyAsync(sums, dSums, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    int scale_weights(double scale) override
+    {
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        hipLaunchKernelGGL(pf_scale_weights_kernel<T>, dim3((np + 255) / 256), dim3(256), 0, stream, dW, np, (T)scale, 0);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    int weights_ptr(void** p) override
+    {
+        if (!p)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_weights_device_ptr: null");
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // the caller will read it from another stream
+        *p = dW;
+        return CSLAM_OK;
+    }
+
+    int get_weights(void* w) override
+    {
+        if (!w)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_get_weights: null");
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(w, dW, (size_t)np * sizeof(T), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    int set_weights(const void* w) override
+    {
+        if (!w)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_set_weights: null");
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(dW, w, (size_t)np * sizeof(T), hipMemcpyHostToDevice, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    int record_bytes(long long* b) override
+    {
+        if (!b)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_record_bytes: null");
+        }
+        *b = (long long)(13 + 6 * nf) * (long long)sizeof(T);
+        return CSLAM_OK;
+    }
+
+    int stage_idx(const int* idx, int count, const char* who)
+    {
+        if (count < 0 || (count > 0 && !idx))
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "%s: bad index list", who);
+        }
+        for (int i = 0; i < count; i++)
+        {
+            if (idx[i] < 0 || idx[i] >= np)
+            {
+                return fail(CSLAM_ERR_BAD_ARG, "%s: index %d outside 0..%d", who, idx[i], np - 1);
+            }
+        }
+        int rc = ensure_m(count);
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(dIdx, idx, (size_t)count * sizeof(int), hipMemcpyHostToDevice, stream));
+        return CSLAM_OK;
+    }
+
+    int pack(const int* idx, int count, void* drec) override
+    {
+        if (count == 0)
+        {
+            return CSLAM_OK;
+        }
+        if (!drec)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_pack: null buffer");
+        }
+        int rc = use_device();
+        if (rc || (rc = stage_idx(idx, count, "pf_pack")))
+        {
+            return rc;
+        }
+        hipLaunchKernelGGL(pf_pack_kernel<T>, dim3(count), dim3(256), 0, stream, store(), dIdx, count,
+                           static_cast<T*>(drec));
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // the buffer is handed to a collective on another stream
+        return CSLAM_OK;
+    }
+
+    int unpack(const int* idx, int count, const void* drec) override
+    {
+        if (count == 0)
+        {
+            return CSLAM_OK;
+        }
+        if (!drec)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_unpack: null buffer");
+        }
+        int rc = use_device();
+        if (rc || (rc = stage_idx(idx, count, "pf_unpack")))
+        {
+            return rc;
+        }
+        hipLaunchKernelGGL(pf_unpack_kernel<T>, dim3(count), dim3(256), 0, stream, store(), dIdx, count,
+                           static_cast<const T*>(drec));
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    // PF.cpp:490-499 for a single shard: slot i <- particle keep[i], weights = w_new
+    int gather_local(const int* keep, double w_new) override
+    {
+        int rc = use_device();
+        if (rc || (rc = stage_idx(keep, np, "pf_gather_local")))
+        {
+            return rc;
+        }
+        hipLaunchKernelGGL(pf_pack_kernel<T>, dim3(np), dim3(256), 0, stream, store(), dIdx, np, dRec);
+        CSLAM_HIP_TRY(hipGetLastError());
+        std::vector<int> ident((size_t)np);
+        for (int i = 0; i < np; i++)
+        {
+            ident[i] = i;
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        CSLAM_HIP_TRY(hipMemcpyAsync(dIdx, ident.data(), (size_t)np * sizeof(int), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(pf_unpack_kernel<T>, dim3(np), dim3(256), 0, stream, store(), dIdx, np, dRec);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return set_uniform_weight(w_new);
+    }
+
+    int get_particle(int i, void* w, void* Xv, void* Pv, void* XF, void* PF) override
+    {
+        if (i < 0 || i >= np)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_get_particle: index %d", i);
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const size_t s = sizeof(T), pitch = (size_t)np * s;
+        if (w)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(w, dW + i, s, hipMemcpyDeviceToHost, stream));
+        }
+        if (Xv)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(Xv, s, dXv + i, pitch, s, 3, hipMemcpyDeviceToHost, stream));
+        }
+        if (Pv)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(Pv, s, dPv + i, pitch, s, 9, hipMemcpyDeviceToHost, stream));
+        }
+        if (XF && nf > 0)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(XF, s, dXF + i, pitch, s, (size_t)2 * nf, hipMemcpyDeviceToHost, stream));
+        }
+        if (PF && nf > 0)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(PF, s, dPF + i, pitch, s, (size_t)4 * nf, hipMemcpyDeviceToHost, stream));
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        return CSLAM_OK;
+    }
+
+    int set_particle(int i, const void* w, const void* Xv, const void* Pv, const void* XF, const void* PF,
+                     int nfeat) override
+    {
+        if (i < 0 || i >= np || nfeat < 0 || nfeat > nfcap)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_set_particle: index %d / nf %d", i, nfeat);
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const size_t s = sizeof(T), pitch = (size_t)np * s;
+        if (w)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(dW + i, w, s, hipMemcpyHostToDevice, stream));
+        }
+        if (Xv)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(dXv + i, pitch, Xv, s, s, 3, hipMemcpyHostToDevice, stream));
+        }
+        if (Pv)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(dPv + i, pitch, Pv, s, s, 9, hipMemcpyHostToDevice, stream));
+        }
+        if (XF && nfeat > 0)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(dXF + i, pitch, XF, s, s, (size_t)2 * nfeat, hipMemcpyHostToDevice, stream));
+        }
+        if (PF && nfeat > 0)
+        {
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(dPF + i, pitch, PF, s, s, (size_t)4 * nfeat, hipMemcpyHostToDevice, stream));
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        nf = nfeat; // every particle of the store carries the same number of features
+        return CSLAM_OK;
+    }
+};
+
+inline PfBase* B(cslam_pf_t h)
+{
+    return reinterpret_cast<PfBase*>(h);
+}
+
+} // namespace
+
+extern "C" {
+
+#define CSLAM_NEED(h)                                                \
+    if (!(h))                                                        \
+    {                                                                \
+        return fail(CSLAM_ERR_BAD_ARG, "%s: null handle", __func__); \
+    }
+
+int cslam_pf_create(int n_particles, int max_features, int dtype, int device, int quirks, cslam_pf_t* out)
+{
+    if (!out || n_particles < 1 || max_features < 0 || (dtype != CSLAM_F32 && dtype != CSLAM_F64) ||
+        (quirks & ~CSLAM_Q_REF_EXACT))
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "pf_create: bad arguments");
+    }
+    *out  = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c == 0)
+    {
+        return fail(CSLAM_ERR_NO_DEVICE, "pf_create: no HIP device (this engine has no CPU fallback)");
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess)
+    {
+        device = 0;
+    }
+    if (device >= c)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "pf_create: device %d of %d", device, c);
+    }
+    PfBase* b = (dtype == CSLAM_F32) ? static_cast<PfBase*>(new (std::nothrow) Pf<float>())
+                                     : static_cast<PfBase*>(new (std::nothrow) Pf<double>());
+    if (!b)
+    {
+        return fail(CSLAM_ERR_ALLOC, "pf_create: out of host memory");
+    }
+    b->dtype  = dtype;
+    b->device = device;
+    b->quirks = quirks;
+    b->np     = n_particles;
+    b->nfcap  = max_features;
+    int rc    = b->init();
+    if (rc)
+    {
+        delete b;
+        return rc;
+    }
+    *out = reinterpret_cast<cslam_pf_t>(b);
+    return CSLAM_OK;
+}
+
+int cslam_pf_destroy(cslam_pf_t h)
+{
+    if (!h)
+    {
+        return CSLAM_OK;
+    }
+    (void)hipSetDevice(B(h)->device);
+    delete B(h);
+    return CSLAM_OK;
+}
+
+int cslam_pf_synchronize(cslam_pf_t h)
+{
+    CSLAM_NEED(h);
+    CSLAM_HIP_TRY(hipSetDevice(B(h)->device));
+    CSLAM_HIP_TRY(hipStreamSynchronize(B(h)->stream));
+    return CSLAM_OK;
+}
+
+int cslam_pf_get_counts(cslam_pf_t h, int* n_particles, int* n_features)
+{
+    CSLAM_NEED(h);
+    if (n_particles)
+    {
+        *n_particles = B(h)->np;
+    }
+    if (n_features)
+    {
+        *n_features = B(h)->nf;
+    }
+    return CSLAM_OK;
+}
+
+int cslam_pf_set_uniform_weight(cslam_pf_t h, double w0)
+{
+    CSLAM_NEED(h);
+    return B(h)->set_uniform_weight(w0);
+}
+
+int cslam_pf_predict(cslam_pf_t h, double v, double swa, const void* Q, double wb, double dt)
+{
+    CSLAM_NEED(h);
+    return B(h)->predict(v, swa, Q, wb, dt);
+}
+
+int cslam_pf_observe_heading(cslam_pf_t h, double phi, int use_heading)
+{
+    CSLAM_NEED(h);
+    return B(h)->observe_heading(phi, use_heading);
+}
+
+int cslam_pf_sample_proposal(cslam_pf_t h, const void* Z, int m, const int* idf, const void* R, const void* normals)
+{
+    CSLAM_NEED(h);
+    return B(h)->sample_proposal(Z, m, idf, R, normals);
+}
+
+int cslam_pf_feature_update(cslam_pf_t h, const void* Z, int m, const int* idf, const void* R)
+{
+    CSLAM_NEED(h);
+    return B(h)->feature_update(Z, m, idf, R);
+}
+
+int cslam_pf_add_features(cslam_pf_t h, const void* Z, int q, const void* R)
+{
+    CSLAM_NEED(h);
+    return B(h)->add_features(Z, q, R);
+}
+
+int cslam_pf_weight_sums(cslam_pf_t h, double* sums)
+{
+    CSLAM_NEED(h);
+    return B(h)->weight_sums(sums);
+}
+
+int cslam_pf_scale_weights(cslam_pf_t h, double scale)
+{
+    CSLAM_NEED(h);
+    return B(h)->scale_weights(scale);
+}
+
+int cslam_pf_weights_device_ptr(cslam_pf_t h, void** dptr)
+{
+    CSLAM_NEED(h);
+    return B(h)->weights_ptr(dptr);
+}
+
+int cslam_pf_get_weights(cslam_pf_t h, void* w_host)
+{
+    CSLAM_NEED(h);
+    return B(h)->get_weights(w_host);
+}
+
+int cslam_pf_set_weights(cslam_pf_t h, const void* w_host)
+{
+    CSLAM_NEED(h);
+    return B(h)->set_weights(w_host);
+}
+
+int cslam_pf_record_bytes(cslam_pf_t h, long long* bytes)
+{
+    CSLAM_NEED(h);
+    return B(h)->record_bytes(bytes);
+}
+
+int cslam_pf_pack(cslam_pf_t h, const int* src_idx, int count, void* d_records)
+{
+    CSLAM_NEED(h);
+    return B(h)->pack(src_idx, count, d_records);
+}
+
+int cslam_pf_unpack(cslam_pf_t h, const int* dst_idx, int count, const void* d_records)
+{
+    CSLAM_NEED(h);
+    return B(h)->unpack(dst_idx, count, d_records);
+}
+
+int cslam_pf_gather_local(cslam_pf_t h, const int* keep, double w_new)
+{
+    CSLAM_NEED(h);
+    if (!keep)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "pf_gather_local: null");
+    }
+    return B(h)->gather_local(keep, w_new);
+}
+
+int cslam_pf_get_particle(cslam_pf_t h, int index, void* w, void* Xv, void* Pv, void* XF, void* PF)
+{
+    CSLAM_NEED(h);
+    return B(h)->get_particle(index, w, Xv, Pv, XF, PF);
+}
+
+int cslam_pf_set_particle(cslam_pf_t h, int index, const void* w, const void* Xv, const void* Pv, const void* XF,
+                          const void* PF, int nf)
+{
+    CSLAM_NEED(h);
+    return B(h)->set_particle(index, w, Xv, Pv, XF, PF, nf);
+}
+
+} // extern "C"
