@@ -14,6 +14,7 @@
 
 #include "cslam_common.hpp"
 #include "ekf_kernels.hpp"
+#include "ekf_kernels_fast.hpp"
 #include "host_linalg.hpp"
 
 using namespace cslam;
@@ -66,6 +67,7 @@ struct Ekf : EkfBase
     T*   dGt   = nullptr;
     T*   dV    = nullptr;
     T*   dt_   = nullptr;
+    T*   dU    = nullptr; // u = G*(G^T V), the gain kernel's X update vector
     T*   dScrS = nullptr;
     T*   dScrG = nullptr;
     int* dFlags = nullptr; // [0] sticky, [1] last
@@ -134,9 +136,10 @@ struct Ekf : EkfBase
         (void)hipFree(dGt);
         (void)hipFree(dV);
         (void)hipFree(dt_);
+        (void)hipFree(dU);
         (void)hipFree(dScrS);
         (void)hipFree(dScrG);
-        dPHT = dW1 = dS = dG = dGt = dV = dt_ = dScrS = dScrG = nullptr;
+        dPHT = dW1 = dS = dG = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
     }
 
     int use_device() { CSLAM_HIP_TRY(hipSetDevice(device)); return CSLAM_OK; }
@@ -201,6 +204,7 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMalloc(&dScrG, kk));
         CSLAM_HIP_TRY(hipMalloc(&dV, (size_t)newk * sizeof(T)));
         CSLAM_HIP_TRY(hipMalloc(&dt_, (size_t)newk * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dU, (size_t)newk * sizeof(T)));
         CSLAM_HIP_TRY(hipMemsetAsync(dPHT, 0, pan, stream));
         CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, pan, stream));
         kcap = newk;
@@ -275,6 +279,9 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMemcpyAsync(dX, X, (size_t)nn * sizeof(T), hipMemcpyHostToDevice, stream));
         CSLAM_HIP_TRY(hipMemcpy2DAsync(dP, (size_t)ldp * sizeof(T), P, (size_t)ldph * sizeof(T), (size_t)nn * sizeof(T),
                                        (size_t)nn, hipMemcpyHostToDevice, stream));
+        // panels: rows beyond the new n must read as zero (the tuned gain kernel relies on it)
+        CSLAM_HIP_TRY(hipMemsetAsync(dPHT, 0, (size_t)ldp * kcap * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, (size_t)ldp * kcap * sizeof(T), stream));
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         n = nn;
         return CSLAM_OK;
@@ -416,8 +423,15 @@ struct Ekf : EkfBase
         {
             w = (quirks & CSLAM_Q_PREDICT_NM4) ? (n - 4) : (n - 3);
         }
-        hipLaunchKernelGGL(ekf_predict_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, (T)v, (T)swa, Q[0],
-                           Q[1], Q[2], Q[3], (T)wb, (T)dt, w);
+        if (w > 0)
+        {
+            hipLaunchKernelGGL(ekf_predict_stripe_kernel<T>, dim3((w + 255) / 256), dim3(256), 0, stream, dX, dP, ldp,
+                               (T)v, (T)swa, (T)dt, w);
+            CSLAM_HIP_TRY(hipGetLastError());
+        }
+        // Pvv and the pose (stripe width 0: the stripe was done above, reading the same old heading)
+        hipLaunchKernelGGL(ekf_predict_kernel<T>, dim3(1), dim3(64), 0, stream, dX, dP, ldp, n, (T)v, (T)swa, Q[0], Q[1],
+                           Q[2], Q[3], (T)wb, (T)dt, 0);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -447,6 +461,30 @@ struct Ekf : EkfBase
         a.scratchS = dScrS;
         a.scratchG = dScrG;
         a.textbook = (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1;
+        a.lds_S    = 1;
+        a.lds_G    = 1;
+        if (k <= 64)
+        {
+            // register-resident factorisation by one wave (ekf_kernels_fast.hpp)
+            if (k <= 4)
+            {
+                hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
+            }
+            else if (k <= 16)
+            {
+                hipLaunchKernelGGL((ekf_factor_small_kernel<T, 16>), dim3(1), dim3(256), 0, stream, a, dU);
+            }
+            else if (k <= 32)
+            {
+                hipLaunchKernelGGL((ekf_factor_small_kernel<T, 32>), dim3(1), dim3(256), 0, stream, a, dU);
+            }
+            else
+            {
+                hipLaunchKernelGGL((ekf_factor_small_kernel<T, 64>), dim3(1), dim3(256), 0, stream, a, dU);
+            }
+            CSLAM_HIP_TRY(hipGetLastError());
+            return CSLAM_OK;
+        }
         size_t mat   = (size_t)k * (k + 1) * sizeof(T);
         size_t small = ((size_t)m * 10 + k) * sizeof(T) + ((size_t)m + 4) * sizeof(int) + 64;
         a.lds_S      = (mat + small <= kLdsBudget) ? 1 : 0;
@@ -460,13 +498,19 @@ struct Ekf : EkfBase
     int launch_gain(int k)
     {
         const int n_pad = round_up(n, kTile);
+        if (launch_gain_fast(k, n_pad))
+        {
+            CSLAM_HIP_TRY(hipGetLastError());
+            return CSLAM_OK;
+        }
         hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
                            dW1, dX);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
 
-    int launch_downdate(int k);
+    int  launch_downdate(int k);
+    bool launch_gain_fast(int k, int n_pad); // MFMA gain (f32, k <= 64 where du is available)
 
     // one batch of m observations with device-resident Z / idf (slam.h:235-266 via EKF.cpp:93-129)
     int batch_on_device(const T* dZ, const int* dIdf, int m, const T* R)
@@ -531,6 +575,15 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMemcpyAsync(dG, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         CSLAM_HIP_TRY(hipMemcpyAsync(dGt, Gt.data(), Gt.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         CSLAM_HIP_TRY(hipMemcpyAsync(dt_, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        std::vector<T> u((size_t)k, (T)0);
+        for (int q = 0; q < k; q++)
+        {
+            for (int c = 0; c < k; c++)
+            {
+                u[q] += G[(size_t)c * k + q] * t[c];
+            }
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(dU, u.data(), u.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         int rc;
         if ((rc = launch_gain(k)) || (rc = launch_downdate(k)))
         {
@@ -723,9 +776,33 @@ template <>
 int Ekf<float>::launch_downdate(int k)
 {
     const int tiles = round_up(n, kTile) / kTile;
-    hipLaunchKernelGGL(ekf_downdate_f32, dim3(tiles * tiles), dim3(256), 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    if (k <= 8)
+    {
+        hipLaunchKernelGGL(ekf_downdate2_f32<8>, dim3(tiles * tiles), dim3(256), 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    }
+    else
+    {
+        hipLaunchKernelGGL(ekf_downdate2_f32<32>, dim3(tiles * tiles), dim3(256), 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    }
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
+}
+
+template <>
+bool Ekf<float>::launch_gain_fast(int k, int n_pad)
+{
+    if (k > 64)
+    {
+        return false; // du is produced by the register-resident factor kernel only
+    }
+    hipLaunchKernelGGL(ekf_gain_mfma_f32, dim3(n_pad / kTile), dim3(256), 0, stream, dPHT, ldp, n, k, dGt, dU, dW1, dX);
+    return true;
+}
+
+template <>
+bool Ekf<double>::launch_gain_fast(int, int)
+{
+    return false;
 }
 
 template <>

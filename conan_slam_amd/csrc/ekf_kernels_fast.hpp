@@ -1,0 +1,477 @@
+// ekf_kernels_fast.hpp -- the tuned gfx950 kernels of the update chain (same arithmetic as the general
+// kernels in ekf_kernels.hpp, which remain the path for shapes these do not cover).
+//
+//   ekf_factor_small_kernel<T,K>  k <= K <= 64: S build by the whole workgroup, then ONE wave holds the
+//                                 matrix a row per lane in registers; Cholesky and the triangular inverse
+//                                 broadcast with v_readlane instead of LDS + barriers.
+//   ekf_gain_mfma_f32             W1 = PHT*G on v_mfma_f32_32x32x2_f32, X += PHT*u fused (u = G G^T V).
+//   ekf_downdate2_f32             P -= W1*W1^T with the P tile prefetched behind the MFMA loop.
+//   ekf_predict_stripe/pose       EKF.cpp:406-455 split so that the O(n) stripe runs on many CUs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ekf_kernels.hpp"
+
+namespace cslam
+{
+
+// ------------------------------------------------------------------------------------------------
+// wave-level broadcast of lane `src`'s value (src is a compile-time constant after unrolling)
+// ------------------------------------------------------------------------------------------------
+__device__ inline float bcast(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ inline double bcast(double v, int src)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2+K3 for k <= K (K a power of two <= 64).  Same outputs as ekf_factor_kernel plus du = G*(G^T V).
+// Padding rows/columns [k, K) of S are the identity, so L and inv(L) are blkdiag(., I).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, T* __restrict__ du)
+{
+    constexpr int LD = K + 1;
+    __shared__ T   S[K * LD];
+    __shared__ T   coef[(K / 2) * 10];
+    __shared__ T   V[K];
+    __shared__ T   tvec[K];
+    __shared__ int fxs[K / 2];
+    __shared__ int sflg[2];
+    const int      k   = 2 * a.m;
+    const int      tid = threadIdx.x;
+
+    if (tid == 0)
+    {
+        sflg[0] = 0;
+        sflg[1] = 0;
+    }
+    if (tid < K)
+    {
+        V[tid] = (T)0;
+    }
+    __syncthreads();
+    for (int o = tid; o < a.m; o += 256)
+    {
+        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    __syncthreads();
+    // S = H*PHT + RR (slam.h:244): 5-term sums in ascending column order; identity padding
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int r = e & (K - 1);
+        const int c = e / K;
+        T         v;
+        if (r < k && c < k)
+        {
+            const int ob = r >> 1, ra = r & 1;
+            const T*  cf = &coef[ob * 10 + ra * 5];
+            const int fx = fxs[ob];
+            const T*  ph = a.PHT + (size_t)c * a.ldw;
+            T         s  = cf[0] * ph[0];
+            s += cf[1] * ph[1];
+            s += cf[2] * ph[2];
+            s += cf[3] * ph[fx];
+            s += cf[4] * ph[fx + 1];
+            v = s + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0);
+        }
+        else
+        {
+            v = (r == c) ? (T)1 : (T)0;
+        }
+        S[r + c * LD] = v;
+    }
+    __syncthreads();
+    // makeSymmetric (slam.h:776-779)
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int r = e & (K - 1);
+        const int c = e / K;
+        if (r > c)
+        {
+            T v           = (S[r + c * LD] + S[c + r * LD]) * (T)0.5;
+            S[r + c * LD] = v;
+            S[c + r * LD] = v;
+        }
+        else if (r == c)
+        {
+            T d           = S[r + c * LD];
+            S[r + c * LD] = (d + d) * (T)0.5;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < k * k; e += 256)
+    {
+        a.dS[e] = S[(e % k) + (e / k) * LD];
+    }
+    __syncthreads();
+
+    if (tid < 64) // ---------------- one wave: lane = row of S / column of inv(L)
+    {
+        const int lane = tid;
+        T         row[K];
+#pragma unroll
+        for (int c = 0; c < K; c++)
+        {
+            row[c] = (lane < K) ? S[lane + c * LD] : ((c == lane) ? (T)1 : (T)0);
+        }
+        bool failed = false;
+        // right-looking lower Cholesky; a pivot <= 0 is the LLT failure of slam.h:421
+#pragma unroll
+        for (int j = 0; j < K; j++)
+        {
+            if (!failed)
+            {
+                const T dj = bcast(row[j], j);
+                if (dj <= (T)0)
+                {
+                    failed = true;
+                }
+                else
+                {
+                    const T sj = dsqrt(dj);
+                    row[j]     = (lane == j) ? sj : row[j] / sj;
+#pragma unroll
+                    for (int c = j + 1; c < K; c++)
+                    {
+                        const T l = bcast(row[j], c);
+                        row[c] -= row[j] * l;
+                    }
+                }
+            }
+        }
+        // inv(L) by forward substitution, lane = column; L[r][q] is lane r's register q
+        T    x[K];
+        bool bad = false;
+        if (!failed)
+        {
+#pragma unroll
+            for (int r = 0; r < K; r++)
+            {
+                T s = (T)0;
+#pragma unroll
+                for (int q = 0; q < r; q++)
+                {
+                    s += bcast(row[q], r) * x[q];
+                }
+                const T d = bcast(row[r], r);
+                x[r]      = (((lane == r) ? (T)1 : (T)0) - s) / d;
+                bad       = bad || !dfinite(x[r]);
+            }
+            bad = (__ballot(bad && lane < k) != 0ull);
+        }
+        const bool zero = failed || bad;
+        // G back into LDS (over S): REF_EXACT G = inv(L) -> G[r][c] = x[r] of lane c; TEXTBOOK G = inv(L)^T
+        if (lane < K)
+        {
+#pragma unroll
+            for (int r = 0; r < K; r++)
+            {
+                const T g = zero ? (T)0 : x[r];
+                if (a.textbook)
+                {
+                    S[lane + r * LD] = g; // G[c][r] = inv(L)[r][c]
+                }
+                else
+                {
+                    S[r + lane * LD] = g;
+                }
+            }
+        }
+        if (lane == 0)
+        {
+            sflg[0] = failed ? 1 : 0;
+            sflg[1] = (!failed && bad) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    // outputs: G, G^T (coalesced), t = G^T V, u = G t
+    for (int e = tid; e < k * k; e += 256)
+    {
+        const int r = e % k, c = e / k;
+        a.dG[r + c * k] = S[r + c * LD];
+    }
+    for (int e = tid; e < k * k; e += 256)
+    {
+        const int c = e % k, r = e / k;
+        a.dGt[c + r * k] = S[r + c * LD];
+    }
+    if (tid < K)
+    {
+        T s = (T)0;
+        if (tid < k)
+        {
+            for (int r = 0; r < k; r++)
+            {
+                s += S[r + tid * LD] * V[r];
+            }
+            a.dt[tid] = s;
+        }
+        tvec[tid] = s;
+    }
+    __syncthreads();
+    if (tid < k)
+    {
+        T s = (T)0;
+        for (int c = 0; c < k; c++)
+        {
+            s += S[tid + c * LD] * tvec[c];
+        }
+        du[tid] = s;
+    }
+    if (tid == 0)
+    {
+        const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
+        a.flags[1]     = code;
+        if (code)
+        {
+            atomicOr(&a.flags[0], code);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 (f32) on MFMA: W1 = PHT * G (slam.h:257), X += PHT * u with u = G*(G^T V) (slam.h:258-259 regrouped).
+// Tile = 128 rows x 32 columns per wave, rows interleaved 4-per-lane exactly as in the downdate so that
+// PHT is read and W1 written with 16-byte accesses.  D[i][j]: i <-> output column, j <-> row slot.
+//   A[i = lane&31][kq = lane>>5] = G[q0+kq][c0+i]   (read from Gt, contiguous across lanes)
+//   B[kq][j]                     = PHT[row0 + 4j + b][q0+kq]
+// PHT rows >= n are zero (never written), so W1's padding rows come out zero as the downdate needs.
+// grid = n_pad/128 workgroups of 4 waves; wave w takes column tiles w, w+4, ...; wave 0 also does X.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ekf_gain_mfma_f32(const float* __restrict__ PHT, int ldw, int n, int k,
+                                                          const float* __restrict__ Gt, const float* __restrict__ u,
+                                                          float* __restrict__ W1, float* __restrict__ X)
+{
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int row0 = blockIdx.x * 128;
+    const int nct  = (k + 31) / 32;
+
+    for (int ct = wave; ct < nct; ct += 4)
+    {
+        const int  c0  = ct * 32;
+        const bool cok = (c0 + lj) < k;
+        f32x16     acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+        float      xs0 = 0.f, xs1 = 0.f, xs2 = 0.f, xs3 = 0.f;
+        const bool dox = (ct == 0);
+        for (int qb = 0; qb < k; qb += 16)
+        {
+            // 8 k-pairs per trip with a compile-time inner trip count; pairs beyond k feed zeros
+#pragma unroll
+            for (int qq = 0; qq < 16; qq += 2)
+            {
+                const int  q  = qb + qq + lh;
+                const bool ok = q < k;
+                float4     b  = make_float4(0.f, 0.f, 0.f, 0.f);
+                float      g  = 0.f;
+                if (ok)
+                {
+                    b = *reinterpret_cast<const float4*>(PHT + (size_t)q * ldw + row0 + 4 * lj);
+                    g = cok ? Gt[(size_t)q * k + c0 + lj] : 0.f;
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, b.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, b.y, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, b.z, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, b.w, acc3, 0, 0, 0);
+                if (dox && ok)
+                {
+                    const float uq = u[q];
+                    xs0 += b.x * uq;
+                    xs1 += b.y * uq;
+                    xs2 += b.z * uq;
+                    xs3 += b.w * uq;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int col = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (col < k)
+            {
+                float4 v = make_float4(acc0[r], acc1[r], acc2[r], acc3[r]);
+                *reinterpret_cast<float4*>(W1 + (size_t)col * ldw + row0 + 4 * lj) = v;
+            }
+        }
+        if (dox)
+        {
+            xs0 += __shfl_xor(xs0, 32);
+            xs1 += __shfl_xor(xs1, 32);
+            xs2 += __shfl_xor(xs2, 32);
+            xs3 += __shfl_xor(xs3, 32);
+            if (lh == 0)
+            {
+                const int r = row0 + 4 * lj;
+                if (r + 0 < n) X[r + 0] += xs0;
+                if (r + 1 < n) X[r + 1] += xs1;
+                if (r + 2 < n) X[r + 2] += xs2;
+                if (r + 3 < n) X[r + 3] += xs3;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f32), version 2.  Same tiling and MFMA mapping as ekf_downdate_f32; differences:
+//   * the 128x128 P tile (16 x 16-byte loads per lane) is requested right after the first W1 panel and
+//     consumed only in the epilogue, so its HBM latency hides behind the MFMA loop.  The panel loads are
+//     issued BEFORE the P loads: vmcnt retires in order, so the wait for the panel leaves the 16 younger
+//     P loads in flight;
+//   * the k loop has a compile-time trip count per chunk (LDS rows beyond k are zero) and is fully unrolled.
+// KC = k-chunk staged in LDS: 2 * KC * 128 * 4 B (KC = 32 -> 32 KiB).
+// ------------------------------------------------------------------------------------------------
+template <int KC>
+__global__ void __launch_bounds__(256, 2) ekf_downdate2_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
+                                                             int ldw, int k, int tiles)
+{
+    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
+    float* sB = s_pan;            // rows of the tile
+    float* sA = s_pan + KC * 128; // columns of the tile
+
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int tj   = blockIdx.x / tiles;
+    const int ti   = blockIdx.x % tiles;
+    const int row0 = ti * 128;
+    const int col0 = tj * 128;
+
+    constexpr int NLD = (KC * 32) / 256; // float4 per thread per panel
+    float4        stB[NLD], stA[NLD];
+
+    // ---- first panel chunk: issue its loads
+#pragma unroll
+    for (int it = 0; it < NLD; it++)
+    {
+        const int id = tid + it * 256;
+        const int kk = id >> 5;
+        const int r4 = (id & 31) * 4;
+        if (kk < k)
+        {
+            const float* w = W1 + (size_t)kk * ldw;
+            stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
+            stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
+        }
+        else
+        {
+            stB[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            stA[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // ---- then the P tile (younger loads: stay in flight across the panel wait)
+    float4 pv[16];
+    float* pbase = P + (size_t)(col0 + wave * 32 + 4 * lh) * ldp + row0 + 4 * lj;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        pv[r] = *reinterpret_cast<const float4*>(pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp);
+    }
+
+    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+
+    for (int k0 = 0; k0 < k; k0 += KC)
+    {
+        if (k0 > 0)
+        {
+            __syncthreads(); // everyone is done reading the previous chunk
+#pragma unroll
+            for (int it = 0; it < NLD; it++)
+            {
+                const int id = tid + it * 256;
+                const int kk = k0 + (id >> 5);
+                const int r4 = (id & 31) * 4;
+                if (kk < k)
+                {
+                    const float* w = W1 + (size_t)kk * ldw;
+                    stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
+                    stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
+                }
+                else
+                {
+                    stB[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    stA[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; it++)
+        {
+            const int id = tid + it * 256;
+            *reinterpret_cast<float4*>(&sB[id * 4]) = stB[it];
+            *reinterpret_cast<float4*>(&sA[id * 4]) = stA[it];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2)
+        {
+            const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + lh) * 128 + 4 * lj]);
+            const float  a = sA[(kk + lh) * 128 + wave * 32 + lj];
+            acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+            acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+            acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+            acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        float4 v = pv[r];
+        v.x -= acc0[r];
+        v.y -= acc1[r];
+        v.z -= acc2[r];
+        v.w -= acc3[r];
+        *reinterpret_cast<float4*>(pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 split: (a) the cross-covariance stripe on many CUs (reads the old heading, writes only the stripe),
+// (b) a one-wave kernel for Pvv and the pose.  Stream order makes (b) see the old pose as (a) did.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_predict_stripe_kernel(const T* __restrict__ X, T* __restrict__ P, int ldp, T v,
+                                                                  T swa, T dt, int stripe_w)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= stripe_w)
+    {
+        return;
+    }
+    const T phi = X[2];
+    const T g02 = -v * dt * dsin(swa + phi); // Gv = [[1,0,g02],[0,1,g12],[0,0,1]]  (EKF.cpp:419-428)
+    const T g12 = v * dt * dcos(swa + phi);
+    const int c  = 3 + j;
+    const T   a0 = P[(size_t)c * ldp + 0], a1 = P[(size_t)c * ldp + 1], a2 = P[(size_t)c * ldp + 2];
+    // rows of Gv * stripe in the dense summation order (zeros of Gv included)
+    T o0 = (T)1 * a0;
+    o0 += (T)0 * a1;
+    o0 += g02 * a2;
+    T o1 = (T)0 * a0;
+    o1 += (T)1 * a1;
+    o1 += g12 * a2;
+    T o2 = (T)0 * a0;
+    o2 += (T)0 * a1;
+    o2 += (T)1 * a2;
+    P[(size_t)c * ldp + 0] = o0;
+    P[(size_t)c * ldp + 1] = o1;
+    P[(size_t)c * ldp + 2] = o2;
+    P[(size_t)0 * ldp + c] = o0;
+    P[(size_t)1 * ldp + c] = o1;
+    P[(size_t)2 * ldp + c] = o2;
+}
+
+} // namespace cslam

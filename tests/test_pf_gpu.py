@@ -1,0 +1,213 @@
+"""GPU parity tests of the FastSLAM-2 per-particle path and of the resample step: the HIP particle store,
+through the C ABI (include/cslam.h), against the CPU oracle particle by particle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from helpers import assert_close
+from pyoracle import Oracle, REF_EXACT, TEXTBOOK
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.float32, np.float64]
+TOL = {np.dtype(np.float32): 2e-5, np.dtype(np.float64): 1e-12}
+
+
+def _random_particles(np_, nf, dtype, seed=0):
+    """Well-conditioned particles around a common pose with nf mapped features each."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for _ in range(np_):
+        Xv = np.array([rng.normal(0, 2.0), rng.normal(0, 2.0), rng.normal(0.2, 0.05)], dtype=dtype)
+        A = rng.normal(size=(3, 3)) * np.array([0.3, 0.3, 0.02])[:, None]
+        Pv = np.asfortranarray((A @ A.T + np.diag([0.05, 0.05, 1e-4])).astype(dtype))
+        XF = np.asfortranarray(rng.uniform(-300, 300, size=(2, nf)).astype(dtype))
+        PF = np.zeros((4, nf), dtype=dtype, order="F")
+        for f in range(nf):
+            B = rng.normal(size=(2, 2)) * 0.5
+            PF[:, f] = (B @ B.T + 0.2 * np.eye(2)).reshape(-1, order="F")
+        w = dtype(rng.uniform(0.5, 1.5) / np_)
+        parts.append([w, Xv, Pv, XF, PF])
+    return parts
+
+
+def _shard_from(parts, nfcap, dtype, quirks=REF_EXACT):
+    from conan_slam_amd.pf import ParticleShard
+
+    sh = ParticleShard(len(parts), nfcap, dtype=dtype, quirks=quirks)
+    for i, (w, Xv, Pv, XF, PF) in enumerate(parts):
+        sh.set_particle(i, w, Xv, Pv, XF, PF)
+    return sh
+
+
+def _obs_for(parts, idf, dtype, seed=3):
+    """Observations of the listed features as seen from the mean particle pose (+ noise)."""
+    rng = np.random.default_rng(seed)
+    X = np.mean([p[1] for p in parts], axis=0).astype(np.float64)
+    XF = parts[0][3].astype(np.float64)
+    Z = np.zeros((2, len(idf)))
+    for i, f in enumerate(idf):
+        dx, dy = XF[0, f - 1] - X[0], XF[1, f - 1] - X[1]
+        Z[0, i] = np.hypot(dx, dy) + rng.normal() * 0.2
+        Z[1, i] = np.arctan2(dy, dx) - X[2] + rng.normal() * 0.01
+    return np.asfortranarray(Z.astype(dtype))
+
+
+def _compare(sh, parts, dtype, tag, wtol=None):
+    tol = TOL[np.dtype(dtype)]
+    for i, (w, Xv, Pv, XF, PF) in enumerate(parts):
+        gw, gX, gP, gXF, gPF = sh.get_particle(i)
+        assert_close(f"{tag} Xv[{i}]", gX, Xv, tol)
+        assert_close(f"{tag} Pv[{i}]", gP, Pv, tol)
+        assert_close(f"{tag} XF[{i}]", gXF, XF, tol)
+        assert_close(f"{tag} PF[{i}]", gPF, PF, tol)
+        rel = abs(float(gw) - float(w)) / max(abs(float(w)), 1e-300)
+        assert rel <= (wtol if wtol is not None else 50 * tol), (tag, i, float(gw), float(w))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_initial_state_and_roundtrip(gpu_required, dtype):
+    from conan_slam_amd.pf import ParticleShard
+
+    sh = ParticleShard(10, 4, dtype=dtype, n_global=40)
+    w, Xv, Pv, XF, PF = sh.get_particle(3)
+    assert w == dtype(1.0 / 40) and not Xv.any() and not Pv.any() and XF.shape == (2, 0)  # PF.cpp:319-341
+    parts = _random_particles(10, 3, dtype, seed=1)
+    sh2 = _shard_from(parts, 5, dtype)
+    _compare(sh2, parts, dtype, "roundtrip", wtol=0.0)
+    sh.close()
+    sh2.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_predict_and_heading(gpu_required, dtype):
+    o = Oracle(dtype)
+    parts = _random_particles(70, 2, dtype, seed=2)
+    sh = _shard_from(parts, 2, dtype)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    for step in range(3):
+        sh.predict(83.33, 0.04 * step, Q, 73.0, 0.01)
+        for p in parts:
+            o.pf_predict(p[1], p[2], 83.33, 0.04 * step, Q, 73.0, 0.01)
+    _compare(sh, parts, dtype, "predict", wtol=0.0)
+    sh.observe_heading(0.25, True)
+    for p in parts:
+        o.pf_observe_heading(p[1], p[2], 0.25, True)
+    tol = 2e-3 if dtype == np.float32 else 1e-9  # 1 - W[2] cancellation, see test_ekf_gpu.test_observe_heading
+    for i, p in enumerate(parts):
+        _, gX, gP, _, _ = sh.get_particle(i)
+        assert_close("heading Xv", gX, p[1], TOL[np.dtype(dtype)])
+        assert_close("heading Pv", gP, p[2], tol)
+    sh.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", [REF_EXACT, TEXTBOOK])
+@pytest.mark.parametrize("m", [1, 5])
+def test_feature_update(gpu_required, dtype, quirks, m):
+    o = Oracle(dtype, quirks)
+    nf = 8
+    parts = _random_particles(65, nf, dtype, seed=4)
+    sh = _shard_from(parts, nf, dtype, quirks)
+    idf = np.array([2, 7, 1, 5, 8][:m], dtype=np.int32)
+    Z = _obs_for(parts, idf, dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    sh.feature_update(Z, idf, R)
+    for p in parts:
+        o.pf_feature_update(p[1], p[3], p[4], Z, idf, R)
+    _compare(sh, parts, dtype, f"feature_update m={m}", wtol=0.0)
+    sh.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m", [1, 4])
+def test_sample_proposal(gpu_required, dtype, m):
+    o = Oracle(dtype)
+    nf = 6
+    npart = 130
+    parts = _random_particles(npart, nf, dtype, seed=5)
+    sh = _shard_from(parts, nf, dtype)
+    idf = np.array([3, 1, 6, 4][:m], dtype=np.int32)
+    Z = _obs_for(parts, idf, dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    normals = np.random.default_rng(9).normal(size=(3, npart)).astype(dtype)
+    sh.sample_proposal(Z, idf, R, normals)
+    for i, p in enumerate(parts):
+        w = np.array([p[0]], dtype=dtype)
+        o.pf_sample_proposal(w, p[1], p[2], p[3], p[4], Z, idf, R, normals[:, i].copy())
+        p[0] = w[0]
+    # the weight is a product of Gaussian densities: compare relatively
+    _compare(sh, parts, dtype, f"sample_proposal m={m}", wtol=5e-3 if dtype == np.float32 else 1e-9)
+    sh.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_features(gpu_required, dtype):
+    from conan_slam_amd import CslamError, _capi
+
+    o = Oracle(dtype)
+    parts = _random_particles(33, 2, dtype, seed=6)
+    sh = _shard_from(parts, 5, dtype)
+    Zn = np.asfortranarray(np.array([[120.0, 300.0, 45.0], [0.3, -1.1, 2.0]], dtype=dtype))
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    sh.add_features(Zn, R)
+    assert sh.n_features == 5
+    for p in parts:
+        XF = np.zeros((2, 5), dtype=dtype, order="F")
+        PF = np.zeros((4, 5), dtype=dtype, order="F")
+        XF[:, :2], PF[:, :2] = p[3], p[4]
+        nf = o.pf_add_features(p[1], XF, PF, 2, Zn, R)
+        assert nf == 5
+        p[3], p[4] = XF, PF
+    _compare(sh, parts, dtype, "add_features", wtol=0.0)
+    with pytest.raises(CslamError) as ei:
+        sh.add_features(Zn[:, :1], R)
+    assert ei.value.code == _capi.ERR_CAPACITY
+    sh.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("force", [True, False])
+def test_resample_single_shard(gpu_required, dtype, force):
+    """PF.cpp:473-500 on one shard against the oracle's corrected normalise/resample."""
+    from conan_slam_amd.pf import SingleComm, resample_particles, stratified_random
+
+    o = Oracle(dtype)
+    npart, nf = 64, 3
+    parts = _random_particles(npart, nf, dtype, seed=7)
+    rng = np.random.default_rng(8)
+    w = rng.uniform(0.0, 1.0, npart) ** (6 if force else 0.05)  # skewed weights => small Neff
+    for p, wi in zip(parts, w):
+        p[0] = dtype(wi)
+    sh = _shard_from(parts, nf, dtype)
+    u = rng.uniform(size=npart)
+    select = stratified_random(npart, u, dtype)
+    assert np.allclose(select, o.pf_stratified_random(npart, u.astype(dtype), ref_exact=False), rtol=1e-6)
+    neff, did = resample_particles(sh, SingleComm(), int(0.75 * npart), True, select=select)
+    wref = np.array([p[0] for p in parts], dtype=dtype)
+    neff_ref, did_ref, keep = o.pf_normalize_resample(wref, int(0.75 * npart), True, select)
+    assert did == did_ref == force
+    assert abs(neff - float(neff_ref)) <= 1e-3 * float(neff_ref)
+    new = [[wref[i], *[a.copy() for a in parts[keep[i]][1:]]] for i in range(npart)] if did else \
+        [[wref[i], *parts[i][1:]] for i in range(npart)]
+    _compare(sh, new, dtype, "resample", wtol=1e-5)
+    sh.close()
+
+
+def test_pack_unpack_roundtrip(gpu_required):
+    import torch
+
+    dtype = np.float32
+    parts = _random_particles(20, 4, dtype, seed=11)
+    sh = _shard_from(parts, 6, dtype)
+    src = np.array([5, 5, 0, 19, 7], dtype=np.int32)
+    buf = sh.pack(src)
+    assert buf.shape == (5, 13 + 6 * 4)
+    host = buf.cpu().numpy()
+    assert host[0, 0] == parts[5][0] and np.array_equal(host[3, 1:4], parts[19][1])
+    dst = np.array([1, 2, 3, 4, 6], dtype=np.int32)
+    sh.unpack(dst, buf)
+    torch.cuda.synchronize()
+    for d, s in zip(dst, src):
+        gw, gX, gP, gXF, gPF = sh.get_particle(int(d))
+        assert gw == parts[s][0] and np.array_equal(gX, parts[s][1]) and np.array_equal(gPF, parts[s][4])
+    sh.close()
