@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -36,6 +37,7 @@ struct EkfBase
     int         ldp      = 0; // padded leading dimension / column count
     int         n        = 3;
     int         sync_mode = 1;
+    int         tune_downdate = 0; // experiment selector (env CSLAM_TUNE_DOWNDATE), 0 = shipped default
     hipStream_t stream   = nullptr;
 
     virtual int init()                                                                        = 0;
@@ -190,7 +192,7 @@ struct Ekf : EkfBase
         {
             return CSLAM_OK;
         }
-        int newk = std::max(k, 2 * kcap);
+        int newk = round_up(std::max(k, 2 * kcap), 8);
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         free_workspace();
         size_t pan = (size_t)ldp * newk * sizeof(T);
@@ -506,6 +508,12 @@ struct Ekf : EkfBase
         hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
                            dW1, dX);
         CSLAM_HIP_TRY(hipGetLastError());
+        const int k8 = round_up(k, 8);
+        if (k8 > k) // the LDS-DMA downdate reads W1 in blocks of 8 columns
+        {
+            CSLAM_HIP_TRY(hipMemset2DAsync(dW1 + (size_t)k * ldp, (size_t)ldp * sizeof(T), 0, (size_t)n_pad * sizeof(T),
+                                           (size_t)(k8 - k), stream));
+        }
         return CSLAM_OK;
     }
 
@@ -776,13 +784,47 @@ template <>
 int Ekf<float>::launch_downdate(int k)
 {
     const int tiles = round_up(n, kTile) / kTile;
+    const dim3 grid(tiles * tiles), block(256);
+    const int  k8 = round_up(k, 8); // W1 columns [k, k8) are zero (gain kernel / memset below)
+    const int  variant = tune_downdate; // 0 default; CSLAM_TUNE_DOWNDATE selects experiments
     if (k <= 8)
     {
-        hipLaunchKernelGGL(ekf_downdate2_f32<8>, dim3(tiles * tiles), dim3(256), 0, stream, dP, ldp, dW1, ldp, k, tiles);
+        hipLaunchKernelGGL((ekf_downdate2_f32<8, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    }
+    else if (variant == 1)
+    {
+        hipLaunchKernelGGL((ekf_downdate2_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    }
+    else if (variant == 2)
+    {
+        hipLaunchKernelGGL((ekf_downdate2_f32<32, true>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    }
+    else if (variant == 4)
+    {
+        hipLaunchKernelGGL(ekf_downdate_f32, grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    }
+    else if (variant == 5)
+    {
+        hipLaunchKernelGGL((ekf_downdate3_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+    }
+    else if (variant == 7)
+    {
+        hipLaunchKernelGGL((ekf_downdate4_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
+    }
+    else if (variant == 8)
+    {
+        hipLaunchKernelGGL((ekf_downdate4_f32<64, true>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
     }
     else
     {
-        hipLaunchKernelGGL(ekf_downdate2_f32<32>, dim3(tiles * tiles), dim3(256), 0, stream, dP, ldp, dW1, ldp, k, tiles);
+        if (k8 <= 32)
+        {
+            hipLaunchKernelGGL((ekf_downdate4_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
+        }
+        else
+        {
+            hipLaunchKernelGGL((ekf_downdate4_f32<64, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
+        }
     }
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
@@ -795,7 +837,8 @@ bool Ekf<float>::launch_gain_fast(int k, int n_pad)
     {
         return false; // du is produced by the register-resident factor kernel only
     }
-    hipLaunchKernelGGL(ekf_gain_mfma_f32, dim3(n_pad / kTile), dim3(256), 0, stream, dPHT, ldp, n, k, dGt, dU, dW1, dX);
+    hipLaunchKernelGGL(ekf_gain_mfma_f32, dim3(n_pad / kTile, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n, k, dGt, dU,
+                       dW1, dX);
     return true;
 }
 
@@ -897,6 +940,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     b->ncap   = 3 + 2 * max_landmarks;
     b->ldp    = round_up(b->ncap, kTile);
     b->n      = 3;
+    if (const char* tv = getenv("CSLAM_TUNE_DOWNDATE"))
+    {
+        b->tune_downdate = atoi(tv);
+    }
     int rc    = b->init();
     if (rc)
     {

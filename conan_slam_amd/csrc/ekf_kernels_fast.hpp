@@ -19,6 +19,8 @@ namespace cslam
 // ------------------------------------------------------------------------------------------------
 // wave-level broadcast of lane `src`'s value (src is a compile-time constant after unrolling)
 // ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __device__ inline float bcast(float v, int src)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -245,80 +247,78 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
 //   A[i = lane&31][kq = lane>>5] = G[q0+kq][c0+i]   (read from Gt, contiguous across lanes)
 //   B[kq][j]                     = PHT[row0 + 4j + b][q0+kq]
 // PHT rows >= n are zero (never written), so W1's padding rows come out zero as the downdate needs.
-// grid = n_pad/128 workgroups of 4 waves; wave w takes column tiles w, w+4, ...; wave 0 also does X.
+// grid = (n_pad/128, ceil(k/32)) single-wave workgroups; column tile 0 also updates X.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ekf_gain_mfma_f32(const float* __restrict__ PHT, int ldw, int n, int k,
-                                                          const float* __restrict__ Gt, const float* __restrict__ u,
-                                                          float* __restrict__ W1, float* __restrict__ X)
+__global__ void __launch_bounds__(64) ekf_gain_mfma_f32(const float* __restrict__ PHT, int ldw, int n, int k,
+                                                         const float* __restrict__ Gt, const float* __restrict__ u,
+                                                         float* __restrict__ W1, float* __restrict__ X)
 {
-    const int tid  = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int lj   = lane & 31;
-    const int lh   = lane >> 5;
-    const int row0 = blockIdx.x * 128;
-    const int nct  = (k + 31) / 32;
-
-    for (int ct = wave; ct < nct; ct += 4)
+    // one wave per workgroup: grid = (n_pad/128 row tiles, ceil(k/32) column tiles)
+    const int  lane = threadIdx.x;
+    const int  lj   = lane & 31;
+    const int  lh   = lane >> 5;
+    const int  row0 = blockIdx.x * 128;
+    const int  c0   = blockIdx.y * 32;
+    const bool cok  = (c0 + lj) < k;
+    const int  cc   = cok ? (c0 + lj) : (k - 1); // clamped: loads are unconditional, the VALUE is selected
+    const bool dox  = (blockIdx.y == 0);
+    f32x16     acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+    float      xs0 = 0.f, xs1 = 0.f, xs2 = 0.f, xs3 = 0.f;
+    const float* pb = PHT + row0 + 4 * lj;
+    for (int qb = 0; qb < k; qb += 16)
     {
-        const int  c0  = ct * 32;
-        const bool cok = (c0 + lj) < k;
-        f32x16     acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-        float      xs0 = 0.f, xs1 = 0.f, xs2 = 0.f, xs3 = 0.f;
-        const bool dox = (ct == 0);
-        for (int qb = 0; qb < k; qb += 16)
-        {
-            // 8 k-pairs per trip with a compile-time inner trip count; pairs beyond k feed zeros
+        // 8 k-pairs per trip, all 16 loads issued before the first MFMA; pairs beyond k contribute zeros
+        float4 b[8];
+        float  g[8], uq[8];
 #pragma unroll
-            for (int qq = 0; qq < 16; qq += 2)
-            {
-                const int  q  = qb + qq + lh;
-                const bool ok = q < k;
-                float4     b  = make_float4(0.f, 0.f, 0.f, 0.f);
-                float      g  = 0.f;
-                if (ok)
-                {
-                    b = *reinterpret_cast<const float4*>(PHT + (size_t)q * ldw + row0 + 4 * lj);
-                    g = cok ? Gt[(size_t)q * k + c0 + lj] : 0.f;
-                }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, b.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, b.y, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, b.z, acc2, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, b.w, acc3, 0, 0, 0);
-                if (dox && ok)
-                {
-                    const float uq = u[q];
-                    xs0 += b.x * uq;
-                    xs1 += b.y * uq;
-                    xs2 += b.z * uq;
-                    xs3 += b.w * uq;
-                }
-            }
+        for (int t = 0; t < 8; t++)
+        {
+            const int q  = qb + 2 * t + lh;
+            const int qc = (q < k) ? q : (k - 1);
+            b[t]         = *reinterpret_cast<const float4*>(pb + (size_t)qc * ldw);
+            g[t]         = Gt[(size_t)qc * k + cc];
+            uq[t]        = u[qc];
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++)
+        for (int t = 0; t < 8; t++)
         {
-            const int col = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (col < k)
-            {
-                float4 v = make_float4(acc0[r], acc1[r], acc2[r], acc3[r]);
-                *reinterpret_cast<float4*>(W1 + (size_t)col * ldw + row0 + 4 * lj) = v;
-            }
+            const int  q  = qb + 2 * t + lh;
+            const bool ok = q < k;
+            const float gg = (ok && cok) ? g[t] : 0.f;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].w, acc3, 0, 0, 0);
+            const float uu = ok ? uq[t] : 0.f;
+            xs0 += b[t].x * uu;
+            xs1 += b[t].y * uu;
+            xs2 += b[t].z * uu;
+            xs3 += b[t].w * uu;
         }
-        if (dox)
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        const int col = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (col < ((k + 7) & ~7)) // columns [k, round_up(k,8)) are written as zeros for the downdate
         {
-            xs0 += __shfl_xor(xs0, 32);
-            xs1 += __shfl_xor(xs1, 32);
-            xs2 += __shfl_xor(xs2, 32);
-            xs3 += __shfl_xor(xs3, 32);
-            if (lh == 0)
-            {
-                const int r = row0 + 4 * lj;
-                if (r + 0 < n) X[r + 0] += xs0;
-                if (r + 1 < n) X[r + 1] += xs1;
-                if (r + 2 < n) X[r + 2] += xs2;
-                if (r + 3 < n) X[r + 3] += xs3;
-            }
+            float4 v = (col < k) ? make_float4(acc0[r], acc1[r], acc2[r], acc3[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(W1 + (size_t)col * ldw + row0 + 4 * lj) = v;
+        }
+    }
+    if (dox)
+    {
+        xs0 += __shfl_xor(xs0, 32);
+        xs1 += __shfl_xor(xs1, 32);
+        xs2 += __shfl_xor(xs2, 32);
+        xs3 += __shfl_xor(xs3, 32);
+        if (lh == 0)
+        {
+            const int r = row0 + 4 * lj;
+            if (r + 0 < n) X[r + 0] += xs0;
+            if (r + 1 < n) X[r + 1] += xs1;
+            if (r + 2 < n) X[r + 2] += xs2;
+            if (r + 3 < n) X[r + 3] += xs3;
         }
     }
 }
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) ekf_gain_mfma_f32(const float* __restrict
 //   * the k loop has a compile-time trip count per chunk (LDS rows beyond k are zero) and is fully unrolled.
 // KC = k-chunk staged in LDS: 2 * KC * 128 * 4 B (KC = 32 -> 32 KiB).
 // ------------------------------------------------------------------------------------------------
-template <int KC>
+template <int KC, bool NT>
 __global__ void __launch_bounds__(256, 2) ekf_downdate2_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
                                                              int ldw, int k, int tiles)
 {
@@ -378,7 +378,16 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate2_f32(float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; r++)
     {
-        pv[r] = *reinterpret_cast<const float4*>(pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp);
+        const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+        if (NT)
+        {
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            pv[r]         = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        else
+        {
+            pv[r] = *reinterpret_cast<const float4*>(src);
+        }
     }
 
     f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
@@ -434,7 +443,240 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate2_f32(float* __restrict__ 
         v.y -= acc1[r];
         v.z -= acc2[r];
         v.w -= acc3[r];
-        *reinterpret_cast<float4*>(pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp) = v;
+        float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+        if (NT)
+        {
+            const f32x4 t = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
+        }
+        else
+        {
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f32), version 3.  Per k-chunk: stage the two W1 panels into LDS, barrier, THEN request the P tile
+// (first chunk only) and run the MFMA loop, so the tile's HBM latency hides behind the matrix work while no
+// older load is waited on.  __builtin_amdgcn_sched_barrier pins that order (the loads have no data dependence
+// the scheduler would otherwise respect).  With KC = 64 a k <= 64 update needs one chunk and two barriers.
+// LDS = 2 * KC * 128 * 4 B (64 KiB at KC = 64 -> two workgroups per CU).
+// ------------------------------------------------------------------------------------------------
+template <int KC, bool NT>
+__global__ void __launch_bounds__(256, 2) ekf_downdate3_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
+                                                             int ldw, int k, int tiles)
+{
+    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
+    float* sB = s_pan;            // rows of the tile
+    float* sA = s_pan + KC * 128; // columns of the tile
+
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int tj   = blockIdx.x / tiles;
+    const int ti   = blockIdx.x % tiles;
+    const int row0 = ti * 128;
+    const int col0 = tj * 128;
+
+    constexpr int NLD = (KC * 32) / 256; // float4 per thread per panel
+    float4        pv[16];
+    float*        pbase = P + (size_t)(col0 + wave * 32 + 4 * lh) * ldp + row0 + 4 * lj;
+    f32x16        acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+
+    for (int k0 = 0; k0 < k; k0 += KC)
+    {
+        if (k0 > 0)
+        {
+            __syncthreads(); // everyone is done reading the previous chunk
+        }
+        {
+            float4 stB[NLD], stA[NLD];
+#pragma unroll
+            for (int it = 0; it < NLD; it++)
+            {
+                const int id = tid + it * 256;
+                const int kk = k0 + (id >> 5);
+                const int kc = (kk < k) ? kk : (k - 1); // unconditional load, value selected below
+                const int r4 = (id & 31) * 4;
+                const float* w = W1 + (size_t)kc * ldw;
+                stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
+                stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
+            }
+#pragma unroll
+            for (int it = 0; it < NLD; it++)
+            {
+                const int  id = tid + it * 256;
+                const bool ok = (k0 + (id >> 5)) < k;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&sB[id * 4]) = ok ? stB[it] : z;
+                *reinterpret_cast<float4*>(&sA[id * 4]) = ok ? stA[it] : z;
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 == 0)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+                if (NT)
+                {
+                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                    pv[r]         = make_float4(t[0], t[1], t[2], t[3]);
+                }
+                else
+                {
+                    pv[r] = *reinterpret_cast<const float4*>(src);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2)
+        {
+            const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + lh) * 128 + 4 * lj]);
+            const float  a = sA[(kk + lh) * 128 + wave * 32 + lj];
+            acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+            acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+            acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+            acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        float4 v = pv[r];
+        v.x -= acc0[r];
+        v.y -= acc1[r];
+        v.z -= acc2[r];
+        v.w -= acc3[r];
+        float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+        if (NT)
+        {
+            const f32x4 t = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
+        }
+        else
+        {
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f32), version 4: the W1 panels go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging
+// registers, no ds_write), one 1 KiB piece (two k-rows of 128 floats) per wave-instruction, LDS image
+// lane-linear.  k8 = k rounded up to 8; W1 columns [k, k8) hold zeros (written by the gain kernel), so the
+// MFMA loop runs in blocks of four k-pairs with no tail.  Per chunk: DMA panels, barrier (drains the DMA),
+// request the P tile (first chunk), MFMA blocks; epilogue P -= acc with 16-byte accesses.
+// ------------------------------------------------------------------------------------------------
+template <int KC, bool NT>
+__global__ void __launch_bounds__(256, 2) ekf_downdate4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
+                                                             int ldw, int k8, int tiles)
+{
+    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
+    float* sB = s_pan;            // rows of the tile   [kk][128]
+    float* sA = s_pan + KC * 128; // columns of the tile [kk][128]
+
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int tj   = blockIdx.x / tiles;
+    const int ti   = blockIdx.x % tiles;
+    const int row0 = ti * 128;
+    const int col0 = tj * 128;
+
+    float4 pv[16];
+    float* pbase = P + (size_t)(col0 + wave * 32 + 4 * lh) * ldp + row0 + 4 * lj;
+    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void*       lptr_t;
+
+    auto stage = [&](int k0, int kc) {
+#pragma unroll
+        for (int it = 0; it < KC / 8; it++)
+        {
+            const int kkb = it * 8 + wave * 2; // first of the two k-rows this wave-instruction moves
+            if (kkb < kc)
+            {
+                const float* w = W1 + (size_t)(k0 + kkb + lh) * ldw + 4 * lj;
+                __builtin_amdgcn_global_load_lds((gptr_t)(w + row0), (lptr_t)(sB + kkb * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(w + col0), (lptr_t)(sA + kkb * 128), 16, 0, 0);
+            }
+        }
+    };
+    auto mma = [&](int kc) {
+        for (int kk = 0; kk < kc; kk += 8)
+        {
+#pragma unroll
+            for (int t = 0; t < 8; t += 2)
+            {
+                const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + t + lh) * 128 + 4 * lj]);
+                const float  a = sA[(kk + t + lh) * 128 + wave * 32 + lj];
+                acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+                acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+                acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+                acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- first chunk, with the P tile requested behind the barrier
+    {
+        const int kc = min(KC, k8);
+        stage(0, kc);
+        __syncthreads(); // waits for the DMA (vmcnt) and publishes the panels
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+            if (NT)
+            {
+                const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                pv[r]         = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            else
+            {
+                pv[r] = *reinterpret_cast<const float4*>(src);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(kc);
+    }
+    for (int k0 = KC; k0 < k8; k0 += KC)
+    {
+        const int kc = min(KC, k8 - k0);
+        __syncthreads(); // everyone is done reading the previous chunk
+        stage(k0, kc);
+        __syncthreads();
+        mma(kc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        float4 v = pv[r];
+        v.x -= acc0[r];
+        v.y -= acc1[r];
+        v.z -= acc2[r];
+        v.w -= acc3[r];
+        float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+        if (NT)
+        {
+            const f32x4 t = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
+        }
+        else
+        {
+            *reinterpret_cast<float4*>(dst) = v;
+        }
     }
 }
 

@@ -179,32 +179,3 @@ class EKF:
             check(self._L.cslam_ekf_debug_last_update(self._h, _vp(out["PHT"]), _vp(out["S"]), _vp(out["G"]),
                                                       _vp(out["W1"]), _vp(out["V"]), C.byref(C.c_int(0))))
         return out
-
-
-class EngineBackend:
-    """Adapter giving the HIP engine the surface oracle/sim_driver.run_demo() drives."""
-
-    def __init__(self, dtype=np.float32, quirks=Q_REF_EXACT, max_landmarks=64):
-        self.ekf = EKF(max_landmarks, dtype=dtype, quirks=quirks)
-
-    @property
-    def n(self):
-        return self.ekf.n
-
-    def predict(self, v, swa, Q, wb, dt):
-        self.ekf.predict(v, swa, Q, wb, dt)
-
-    def observe_heading(self, phi, use):
-        self.ekf.observe_heading(phi, use)
-
-    def update(self, Z, R, idf, batch):
-        self.ekf.update(Z, R, idf, batch)
-
-    def augment(self, Z, R):
-        self.ekf.augment(Z, R)
-
-    def get_x(self):
-        return self.ekf.get_x()
-
-    def get_p(self):
-        return self.ekf.get_p()

@@ -119,9 +119,10 @@ class TorchComm:
         return t.cpu().tolist()
 
     def all_gather(self, local):
-        out = self.torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
-        return out.reshape(-1)
+        local = local.contiguous().reshape(-1)
+        out = self.torch.empty(self.world * local.numel(), dtype=local.dtype, device=local.device)
+        self.dist.all_gather_into_tensor(out, local, group=self.group)
+        return out
 
     def all_to_all_v(self, send, send_counts, recv_counts, rec_len):
         out = self.torch.empty((sum(recv_counts), rec_len), dtype=send.dtype, device=send.device)

@@ -87,3 +87,34 @@ class OracleState:
 
     def p(self):
         return np.array(self.P[: self.n, : self.n], order="F")
+
+
+class EngineBackend:
+    """Adapter giving the HIP engine (conan_slam_amd.EKF) the surface sim_driver.run_demo() drives."""
+
+    def __init__(self, dtype=np.float32, quirks=3, max_landmarks=64):
+        from conan_slam_amd import EKF
+
+        self.ekf = EKF(max_landmarks, dtype=dtype, quirks=quirks)
+
+    @property
+    def n(self):
+        return self.ekf.n
+
+    def predict(self, v, swa, Q, wb, dt):
+        self.ekf.predict(v, swa, Q, wb, dt)
+
+    def observe_heading(self, phi, use):
+        self.ekf.observe_heading(phi, use)
+
+    def update(self, Z, R, idf, batch):
+        self.ekf.update(Z, R, idf, batch)
+
+    def augment(self, Z, R):
+        self.ekf.augment(Z, R)
+
+    def get_x(self):
+        return self.ekf.get_x()
+
+    def get_p(self):
+        return self.ekf.get_p()

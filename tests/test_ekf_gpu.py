@@ -353,7 +353,7 @@ def test_update_device_matches_host_entry(gpu_required):
 def test_demo_map_run_matches_oracle(gpu_required):
     """Config 1 (the reference's bundled demo map, test/main.cpp:24-200) driven through the engine: the first
     2400 control steps (400 observation events, map building + updates + heading) against the oracle."""
-    from conan_slam_amd import EngineBackend
+    from helpers import EngineBackend
     from sim_driver import OracleBackend, load_demo_map, run_demo
 
     LM, WP = load_demo_map()
