@@ -83,6 +83,11 @@ struct Ekf : EkfBase
     hipEvent_t  stage_ev[kStagingSlots];
     bool        stage_ev_used[kStagingSlots];
     int         stage_next = 0;
+    // tile list of the persistent symmetric downdate
+    int2* dTiles      = nullptr;
+    int   tiles_built = 0;
+    int   n_sym_tiles = 0;
+    int   num_cus     = 256;
     // status
     int sticky_host = 0; // flags raised by host-side decisions (FALLBACK/SKIPPED)
     int last_k      = 0;
@@ -114,6 +119,7 @@ struct Ekf : EkfBase
         free_workspace();
         (void)hipFree(dFlags);
         (void)hipFree(dHead);
+        (void)hipFree(dTiles);
         (void)hipFree(dStage);
         if (hStage)
         {
@@ -158,6 +164,11 @@ struct Ekf : EkfBase
             return rc;
         }
         CSLAM_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        {
+            hipDeviceProp_t prop;
+            CSLAM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+            num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
         size_t pbytes = (size_t)ldp * ldp * sizeof(T);
         CSLAM_HIP_TRY(hipMalloc(&dX, (size_t)ldp * sizeof(T)));
         CSLAM_HIP_TRY(hipMalloc(&dP, pbytes));
@@ -518,6 +529,7 @@ struct Ekf : EkfBase
     }
 
     int  launch_downdate(int k);
+    int  ensure_tile_list(int tiles);
     bool launch_gain_fast(int k, int n_pad); // MFMA gain (f32, k <= 64 where du is available)
 
     // one batch of m observations with device-resident Z / idf (slam.h:235-266 via EKF.cpp:93-129)
@@ -780,6 +792,34 @@ struct Ekf : EkfBase
     }
 };
 
+// lower-triangular tile list (ti >= tj), column-of-tiles major so that consecutive entries share the column
+// panel; rebuilt when the number of 128-row tiles changes (n grew past a tile boundary)
+template <typename T>
+int Ekf<T>::ensure_tile_list(int tiles)
+{
+    if (tiles == tiles_built)
+    {
+        return CSLAM_OK;
+    }
+    std::vector<int2> h;
+    h.reserve((size_t)tiles * (tiles + 1) / 2);
+    for (int tj = 0; tj < tiles; tj++)
+    {
+        for (int ti = tj; ti < tiles; ti++)
+        {
+            h.push_back(make_int2(ti, tj));
+        }
+    }
+    CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(dTiles);
+    dTiles = nullptr;
+    CSLAM_HIP_TRY(hipMalloc(&dTiles, h.size() * sizeof(int2)));
+    CSLAM_HIP_TRY(hipMemcpy(dTiles, h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice));
+    tiles_built = tiles;
+    n_sym_tiles = (int)h.size();
+    return CSLAM_OK;
+}
+
 template <>
 int Ekf<float>::launch_downdate(int k)
 {
@@ -787,7 +827,7 @@ int Ekf<float>::launch_downdate(int k)
     const dim3 grid(tiles * tiles), block(256);
     const int  k8 = round_up(k, 8); // W1 columns [k, k8) are zero (gain kernel / memset below)
     const int  variant = tune_downdate; // 0 default; CSLAM_TUNE_DOWNDATE selects experiments
-    if (k <= 8)
+    if (variant == 14)
     {
         hipLaunchKernelGGL((ekf_downdate2_f32<8, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
     }
@@ -807,6 +847,33 @@ int Ekf<float>::launch_downdate(int k)
     {
         hipLaunchKernelGGL((ekf_downdate3_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
     }
+    else if (variant == 12 || variant == 13)
+    {
+        int rc = ensure_tile_list(tiles);
+        if (rc)
+        {
+            return rc;
+        }
+        const int G = std::min(n_sym_tiles, 2 * num_cus);
+        if (variant == 12)
+        {
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8, dTiles,
+                               n_sym_tiles);
+        }
+        else
+        {
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, false>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8, dTiles,
+                               n_sym_tiles);
+        }
+    }
+    else if (variant == 10)
+    {
+        hipLaunchKernelGGL((ekf_downdate_sym_f32<32, true>), dim3(tiles, tiles), block, 0, stream, dP, ldp, dW1, ldp, k);
+    }
+    else if (variant == 11)
+    {
+        hipLaunchKernelGGL((ekf_downdate_sym_f32<32, false>), dim3(tiles, tiles), block, 0, stream, dP, ldp, dW1, ldp, k);
+    }
     else if (variant == 7)
     {
         hipLaunchKernelGGL((ekf_downdate4_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
@@ -815,16 +882,21 @@ int Ekf<float>::launch_downdate(int k)
     {
         hipLaunchKernelGGL((ekf_downdate4_f32<64, true>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
     }
+    else if (variant == 9)
+    {
+        hipLaunchKernelGGL((ekf_downdate4_f32<64, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
+    }
     else
     {
-        if (k8 <= 32)
+        // shipped default: persistent, symmetric, non-temporal P accesses
+        int rc = ensure_tile_list(tiles);
+        if (rc)
         {
-            hipLaunchKernelGGL((ekf_downdate4_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
+            return rc;
         }
-        else
-        {
-            hipLaunchKernelGGL((ekf_downdate4_f32<64, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
-        }
+        const int G = std::min(n_sym_tiles, 2 * num_cus);
+        hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8, dTiles,
+                           n_sym_tiles);
     }
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;

@@ -66,30 +66,55 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
         a.dV[2 * o + 1] = V[2 * o + 1];
     }
     __syncthreads();
-    // S = H*PHT + RR (slam.h:244): 5-term sums in ascending column order; identity padding
-    for (int e = tid; e < K * K; e += 256)
+    // S = H*PHT + RR (slam.h:244): 5-term sums in ascending column order; identity padding.
+    // Two passes with compile-time trip counts: first every global load of the thread's elements is issued
+    // (they are independent L2 hits), then the sums are formed -- one round trip instead of one per element.
     {
-        const int r = e & (K - 1);
-        const int c = e / K;
-        T         v;
-        if (r < k && c < k)
+        constexpr int NE = (K * K + 255) / 256;
+        T             ph[NE][5];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
         {
-            const int ob = r >> 1, ra = r & 1;
-            const T*  cf = &coef[ob * 10 + ra * 5];
-            const int fx = fxs[ob];
-            const T*  ph = a.PHT + (size_t)c * a.ldw;
-            T         s  = cf[0] * ph[0];
-            s += cf[1] * ph[1];
-            s += cf[2] * ph[2];
-            s += cf[3] * ph[fx];
-            s += cf[4] * ph[fx + 1];
-            v = s + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0);
+            const int e  = tid + it * 256;
+            const int r  = e & (K - 1);
+            const int c  = e / K;
+            const bool in = (e < K * K) && (r < k) && (c < k);
+            const int rc = in ? r : 0, cc = in ? c : 0; // clamped: loads stay unconditional
+            const int fx = fxs[rc >> 1];
+            const T*  p  = a.PHT + (size_t)cc * a.ldw;
+            ph[it][0]    = p[0];
+            ph[it][1]    = p[1];
+            ph[it][2]    = p[2];
+            ph[it][3]    = p[fx];
+            ph[it][4]    = p[fx + 1];
         }
-        else
+#pragma unroll
+        for (int it = 0; it < NE; it++)
         {
-            v = (r == c) ? (T)1 : (T)0;
+            const int e = tid + it * 256;
+            if (e < K * K)
+            {
+                const int r = e & (K - 1);
+                const int c = e / K;
+                T         v;
+                if (r < k && c < k)
+                {
+                    const int ob = r >> 1, ra = r & 1;
+                    const T*  cf = &coef[ob * 10 + ra * 5];
+                    T         sm = cf[0] * ph[it][0];
+                    sm += cf[1] * ph[it][1];
+                    sm += cf[2] * ph[it][2];
+                    sm += cf[3] * ph[it][3];
+                    sm += cf[4] * ph[it][4];
+                    v = sm + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0);
+                }
+                else
+                {
+                    v = (r == c) ? (T)1 : (T)0;
+                }
+                S[r + c * LD] = v;
+            }
         }
-        S[r + c * LD] = v;
     }
     __syncthreads();
     // makeSymmetric (slam.h:776-779)
@@ -110,9 +135,13 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
         }
     }
     __syncthreads();
-    for (int e = tid; e < k * k; e += 256)
+    for (int e = tid; e < K * K; e += 256)
     {
-        a.dS[e] = S[(e % k) + (e / k) * LD];
+        const int r = e & (K - 1), c = e / K;
+        if (r < k && c < k)
+        {
+            a.dS[r + c * k] = S[r + c * LD];
+        }
     }
     __syncthreads();
 
@@ -196,38 +225,60 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
     }
     __syncthreads();
     // outputs: G, G^T (coalesced), t = G^T V, u = G t
-    for (int e = tid; e < k * k; e += 256)
+    for (int e = tid; e < K * K; e += 256)
     {
-        const int r = e % k, c = e / k;
-        a.dG[r + c * k] = S[r + c * LD];
-    }
-    for (int e = tid; e < k * k; e += 256)
-    {
-        const int c = e % k, r = e / k;
-        a.dGt[c + r * k] = S[r + c * LD];
-    }
-    if (tid < K)
-    {
-        T s = (T)0;
-        if (tid < k)
+        const int r = e & (K - 1), c = e / K;
+        if (r < k && c < k)
         {
-            for (int r = 0; r < k; r++)
+            a.dG[r + c * k] = S[r + c * LD];
+        }
+    }
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int c = e & (K - 1), r = e / K;
+        if (r < k && c < k)
+        {
+            a.dGt[c + r * k] = S[r + c * LD];
+        }
+    }
+    // t = G^T V and u = G t: 4 lanes per output element, partial sums combined in a fixed order
+    {
+        const int o = tid >> 2, part = tid & 3; // 256 threads = 64 outputs x 4 parts
+        T         s = (T)0;
+        if (o < K)
+        {
+#pragma unroll 4
+            for (int r = part; r < K; r += 4)
             {
-                s += S[r + tid * LD] * V[r];
+                s += S[r + o * LD] * V[r]; // padding rows of V are zero
             }
-            a.dt[tid] = s;
         }
-        tvec[tid] = s;
-    }
-    __syncthreads();
-    if (tid < k)
-    {
-        T s = (T)0;
-        for (int c = 0; c < k; c++)
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0 && o < K)
         {
-            s += S[tid + c * LD] * tvec[c];
+            if (o < k)
+            {
+                a.dt[o] = s;
+            }
+            tvec[o] = (o < k) ? s : (T)0;
         }
-        du[tid] = s;
+        __syncthreads();
+        T s2 = (T)0;
+        if (o < K)
+        {
+#pragma unroll 4
+            for (int c = part; c < K; c += 4)
+            {
+                s2 += S[o + c * LD] * tvec[c];
+            }
+        }
+        s2 += __shfl_xor(s2, 1);
+        s2 += __shfl_xor(s2, 2);
+        if (part == 0 && o < k)
+        {
+            du[o] = s2;
+        }
     }
     if (tid == 0)
     {
@@ -333,7 +384,7 @@ __global__ void __launch_bounds__(64) ekf_gain_mfma_f32(const float* __restrict_
 // KC = k-chunk staged in LDS: 2 * KC * 128 * 4 B (KC = 32 -> 32 KiB).
 // ------------------------------------------------------------------------------------------------
 template <int KC, bool NT>
-__global__ void __launch_bounds__(256, 2) ekf_downdate2_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_downdate2_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
                                                              int ldw, int k, int tiles)
 {
     __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
@@ -464,7 +515,7 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate2_f32(float* __restrict__ 
 // LDS = 2 * KC * 128 * 4 B (64 KiB at KC = 64 -> two workgroups per CU).
 // ------------------------------------------------------------------------------------------------
 template <int KC, bool NT>
-__global__ void __launch_bounds__(256, 2) ekf_downdate3_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_downdate3_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
                                                              int ldw, int k, int tiles)
 {
     __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
@@ -575,7 +626,7 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate3_f32(float* __restrict__ 
 // request the P tile (first chunk), MFMA blocks; epilogue P -= acc with 16-byte accesses.
 // ------------------------------------------------------------------------------------------------
 template <int KC, bool NT>
-__global__ void __launch_bounds__(256, 2) ekf_downdate4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_downdate4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
                                                              int ldw, int k8, int tiles)
 {
     __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
@@ -677,6 +728,303 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate4_f32(float* __restrict__ 
         {
             *reinterpret_cast<float4*>(dst) = v;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f32), symmetric form.  W1*W1^T is symmetric and so is P, so only tiles on or below the diagonal
+// (ti >= tj) are computed: half the MFMA work and half the P reads.  An off-diagonal tile's result is stored
+// twice -- in place (16-byte, row-contiguous) and transposed into the mirror tile (tj, ti): for MFMA block b
+// and register group g the four registers 4g..4g+3 of a lane are four consecutive ROWS of the mirror tile in
+// column row0+4*lj+b, i.e. one 16-byte store; a lane pair (lh = 0,1) covers 32 contiguous bytes and the four
+// groups complete a 128-byte line, which L2 merges before it leaves for HBM.
+// Contract: P is symmetric on entry (every kernel of the engine keeps it bitwise symmetric); the strictly
+// upper tiles are overwritten with the mirror of the lower result.
+// grid = tiles x tiles (x = row tile, y = column tile); workgroups above the diagonal exit at once.
+// ------------------------------------------------------------------------------------------------
+template <int KC, bool NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_downdate_sym_f32(float* __restrict__ P, int ldp,
+                                                                const float* __restrict__ W1, int ldw, int k)
+{
+    const int ti = blockIdx.x;
+    const int tj = blockIdx.y;
+    if (ti < tj)
+    {
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
+    float* sB = s_pan;
+    float* sA = s_pan + KC * 128;
+
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int row0 = ti * 128;
+    const int col0 = tj * 128;
+
+    constexpr int NLD = (KC * 32) / 256;
+    float4        stB[NLD], stA[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; it++)
+    {
+        const int id = tid + it * 256;
+        const int kk = id >> 5;
+        const int kc = (kk < k) ? kk : (k - 1);
+        const int r4 = (id & 31) * 4;
+        const float* w = W1 + (size_t)kc * ldw;
+        stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
+        stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
+    }
+    float4 pv[16];
+    float* pbase = P + (size_t)(col0 + wave * 32 + 4 * lh) * ldp + row0 + 4 * lj;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+        if (NT)
+        {
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            pv[r]         = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        else
+        {
+            pv[r] = *reinterpret_cast<const float4*>(src);
+        }
+    }
+
+    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+    for (int k0 = 0; k0 < k; k0 += KC)
+    {
+        if (k0 > 0)
+        {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NLD; it++)
+            {
+                const int id = tid + it * 256;
+                const int kk = k0 + (id >> 5);
+                const int kc = (kk < k) ? kk : (k - 1);
+                const int r4 = (id & 31) * 4;
+                const float* w = W1 + (size_t)kc * ldw;
+                stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
+                stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; it++)
+        {
+            const int    id = tid + it * 256;
+            const bool   ok = (k0 + (id >> 5)) < k;
+            const float4 z  = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sB[id * 4]) = ok ? stB[it] : z;
+            *reinterpret_cast<float4*>(&sA[id * 4]) = ok ? stA[it] : z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2)
+        {
+            const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + lh) * 128 + 4 * lj]);
+            const float  a = sA[(kk + lh) * 128 + wave * 32 + lj];
+            acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+            acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+            acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+            acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+        }
+    }
+    // in-place store of the tile
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        pv[r].x -= acc0[r];
+        pv[r].y -= acc1[r];
+        pv[r].z -= acc2[r];
+        pv[r].w -= acc3[r];
+        float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+        if (NT)
+        {
+            const f32x4 t = {pv[r].x, pv[r].y, pv[r].z, pv[r].w};
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
+        }
+        else
+        {
+            *reinterpret_cast<float4*>(dst) = pv[r];
+        }
+    }
+    // mirror tile (tj, ti): element (row0+4lj+b, col0+32w+8g+4lh+q) of this tile goes to the transposed place
+    if (ti != tj)
+    {
+        float* mbase = P + (size_t)(row0 + 4 * lj) * ldp + col0 + wave * 32 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            const float4 m0 = make_float4(pv[4 * g + 0].x, pv[4 * g + 1].x, pv[4 * g + 2].x, pv[4 * g + 3].x);
+            const float4 m1 = make_float4(pv[4 * g + 0].y, pv[4 * g + 1].y, pv[4 * g + 2].y, pv[4 * g + 3].y);
+            const float4 m2 = make_float4(pv[4 * g + 0].z, pv[4 * g + 1].z, pv[4 * g + 2].z, pv[4 * g + 3].z);
+            const float4 m3 = make_float4(pv[4 * g + 0].w, pv[4 * g + 1].w, pv[4 * g + 2].w, pv[4 * g + 3].w);
+            *reinterpret_cast<float4*>(mbase + (size_t)0 * ldp + 8 * g) = m0;
+            *reinterpret_cast<float4*>(mbase + (size_t)1 * ldp + 8 * g) = m1;
+            *reinterpret_cast<float4*>(mbase + (size_t)2 * ldp + 8 * g) = m2;
+            *reinterpret_cast<float4*>(mbase + (size_t)3 * ldp + 8 * g) = m3;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f32), persistent symmetric form -- the shipped P-GEMM.
+//   * symmetric: only tiles with ti >= tj are computed (half the MFMA work, half the P reads); the result of
+//     an off-diagonal tile is stored in place and transposed into the mirror tile (see ekf_downdate_sym_f32);
+//   * persistent: gridDim.x workgroups (two per CU) walk a host-built tile list with stride gridDim.x, and the
+//     P tile of the NEXT list entry is requested (16 x 16-byte loads per lane into a second register set)
+//     right before the MFMA loop of the current one, so every workgroup keeps 64 KiB of HBM reads in flight
+//     while it computes;
+//   * the W1 panels go global -> LDS by LDS-DMA (no staging registers): one 1 KiB piece = two k-rows of 128
+//     floats per wave-instruction, lane-linear LDS image; k8 = round_up(k, 8), columns [k, k8) of W1 are zero.
+// Register plan per lane: 64 accumulators + 2 x 64 P-tile values; pinned to two waves per SIMD.
+// ------------------------------------------------------------------------------------------------
+template <int KC, bool NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
+                      const int2* __restrict__ tile_list, int ntiles)
+{
+    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
+    float* sB = s_pan;            // rows of the tile   [kk][128]
+    float* sA = s_pan + KC * 128; // columns of the tile [kk][128]
+
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int G    = gridDim.x;
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void*       lptr_t;
+
+    auto tile_base = [&](int2 t) -> float* {
+        return P + (size_t)(t.y * 128 + wave * 32 + 4 * lh) * ldp + t.x * 128 + 4 * lj;
+    };
+    auto load_tile = [&](float* pbase, f32x4 (&pv)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+            if (NT)
+            {
+                pv[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            }
+            else
+            {
+                pv[r] = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+    };
+    // one tile: panels -> LDS, (prefetch next P tile), MFMA, P -= acc, store in place + mirror
+    auto process = [&](int2 cur, f32x4 (&pv)[16], bool have_next, int2 nxt, f32x4 (&pn)[16]) {
+        const int row0 = cur.x * 128;
+        const int col0 = cur.y * 128;
+        f32x16    acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+        for (int k0 = 0; k0 < k8; k0 += KC)
+        {
+            const int kc = min(KC, k8 - k0);
+            __syncthreads(); // previous readers of the panels are done
+#pragma unroll
+            for (int it = 0; it < KC / 8; it++)
+            {
+                const int kkb = it * 8 + wave * 2;
+                if (kkb < kc)
+                {
+                    const float* w = W1 + (size_t)(k0 + kkb + lh) * ldw + 4 * lj;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(w + row0), (lptr_t)(sB + kkb * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(w + col0), (lptr_t)(sA + kkb * 128), 16, 0, 0);
+                }
+            }
+            __syncthreads(); // drains the DMA (vmcnt) and publishes the panels
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 == 0 && have_next)
+            {
+                load_tile(tile_base(nxt), pn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            for (int kk = 0; kk < kc; kk += 8)
+            {
+#pragma unroll
+                for (int t = 0; t < 8; t += 2)
+                {
+                    const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + t + lh) * 128 + 4 * lj]);
+                    const float  a = sA[(kk + t + lh) * 128 + wave * 32 + lj];
+                    acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+                    acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+                    acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+                    acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+                }
+            }
+        }
+        float* pbase = tile_base(cur);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            pv[r][0] -= acc0[r];
+            pv[r][1] -= acc1[r];
+            pv[r][2] -= acc2[r];
+            pv[r][3] -= acc3[r];
+            float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+            if (NT)
+            {
+                __builtin_nontemporal_store(pv[r], reinterpret_cast<f32x4*>(dst));
+            }
+            else
+            {
+                *reinterpret_cast<f32x4*>(dst) = pv[r];
+            }
+        }
+        if (cur.x != cur.y) // mirror tile (tj, ti)
+        {
+            float* mbase = P + (size_t)(row0 + 4 * lj) * ldp + col0 + wave * 32 + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                {
+                    const f32x4 m = {pv[4 * g + 0][b], pv[4 * g + 1][b], pv[4 * g + 2][b], pv[4 * g + 3][b]};
+                    *reinterpret_cast<f32x4*>(mbase + (size_t)b * ldp + 8 * g) = m;
+                }
+            }
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= ntiles)
+    {
+        return;
+    }
+    f32x4 pvA[16], pvB[16];
+    int2   cur = tile_list[t];
+    load_tile(tile_base(cur), pvA);
+    while (true)
+    {
+        int        tn  = t + G;
+        bool       hn  = tn < ntiles;
+        int2       nxt = hn ? tile_list[tn] : cur;
+        process(cur, pvA, hn, nxt, pvB);
+        if (!hn)
+        {
+            break;
+        }
+        t               = tn;
+        cur             = nxt;
+        tn              = t + G;
+        hn              = tn < ntiles;
+        nxt             = hn ? tile_list[tn] : cur;
+        process(cur, pvB, hn, nxt, pvA);
+        if (!hn)
+        {
+            break;
+        }
+        t   = tn;
+        cur = nxt;
     }
 }
 
