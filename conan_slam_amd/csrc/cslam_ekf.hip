@@ -38,6 +38,7 @@ struct EkfBase
     int         n        = 3;
     int         sync_mode = 1;
     int         tune_downdate = 0; // experiment selector (env CSLAM_TUNE_DOWNDATE), 0 = shipped default
+    int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     hipStream_t stream   = nullptr;
 
     virtual int init()                                                                        = 0;
@@ -317,6 +318,12 @@ struct Ekf : EkfBase
         }
         if (P)
         {
+            if (lower && n > kTile)
+            {
+                const int g = (n + 31) / 32;
+                hipLaunchKernelGGL(ekf_mirror_upper_kernel<T>, dim3(g, g), dim3(256), 0, stream, dP, ldp, n);
+                CSLAM_HIP_TRY(hipGetLastError());
+            }
             CSLAM_HIP_TRY(hipMemcpy2DAsync(P, (size_t)ldph * sizeof(T), dP, (size_t)ldp * sizeof(T),
                                            (size_t)n * sizeof(T), (size_t)n, hipMemcpyDeviceToHost, stream));
         }
@@ -439,12 +446,12 @@ struct Ekf : EkfBase
         if (w > 0)
         {
             hipLaunchKernelGGL(ekf_predict_stripe_kernel<T>, dim3((w + 255) / 256), dim3(256), 0, stream, dX, dP, ldp,
-                               (T)v, (T)swa, (T)dt, w);
+                               (T)v, (T)swa, (T)dt, w, lower);
             CSLAM_HIP_TRY(hipGetLastError());
         }
         // Pvv and the pose (stripe width 0: the stripe was done above, reading the same old heading)
         hipLaunchKernelGGL(ekf_predict_kernel<T>, dim3(1), dim3(64), 0, stream, dX, dP, ldp, n, (T)v, (T)swa, Q[0], Q[1],
-                           Q[2], Q[3], (T)wb, (T)dt, 0);
+                           Q[2], Q[3], (T)wb, (T)dt, 0, lower);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -547,7 +554,7 @@ struct Ekf : EkfBase
             return rc;
         }
         hipLaunchKernelGGL(ekf_gather_kernel<T>, dim3((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs), dim3(256), 0,
-                           stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp);
+                           stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp, lower);
         CSLAM_HIP_TRY(hipGetLastError());
         if ((rc = prof_end(CSLAM_STAGE_GATHER)) || (rc = prof_begin(CSLAM_STAGE_FACTOR)) ||
             (rc = launch_factor(dZ, dIdf, m, R)) || (rc = prof_end(CSLAM_STAGE_FACTOR)) ||
@@ -682,7 +689,7 @@ struct Ekf : EkfBase
         for (int i = 0; i < q; i++)
         {
             hipLaunchKernelGGL(ekf_augment_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, Z[2 * i],
-                               Z[2 * i + 1], R[0], R[1], R[2], R[3]);
+                               Z[2 * i + 1], R[0], R[1], R[2], R[3], lower);
             CSLAM_HIP_TRY(hipGetLastError());
             n += 2;
         }
@@ -709,10 +716,10 @@ struct Ekf : EkfBase
         T* rrow = dHead + 2 * (size_t)ldp;
         T* scal = dHead + 3 * (size_t)ldp;
         hipLaunchKernelGGL(ekf_heading_prep_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, (T)phi, R, w, cp2,
-                           rrow, scal);
+                           rrow, scal, lower);
         CSLAM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ekf_heading_apply_kernel<T>, dim3((n + 255) / 256, (n + 15) / 16), dim3(256), 0, stream, dP,
-                           ldp, n, w, cp2, rrow, scal, (T)FLT_MIN);
+                           ldp, n, w, cp2, rrow, scal, (T)FLT_MIN, lower);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -857,13 +864,13 @@ int Ekf<float>::launch_downdate(int k)
         const int G = std::min(n_sym_tiles, 2 * num_cus);
         if (variant == 12)
         {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8, dTiles,
-                               n_sym_tiles);
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8,
+                               dTiles, n_sym_tiles);
         }
         else
         {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, false>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8, dTiles,
-                               n_sym_tiles);
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, false, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8,
+                               dTiles, n_sym_tiles);
         }
     }
     else if (variant == 10)
@@ -895,8 +902,16 @@ int Ekf<float>::launch_downdate(int k)
             return rc;
         }
         const int G = std::min(n_sym_tiles, 2 * num_cus);
-        hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8, dTiles,
-                           n_sym_tiles);
+        if (lower)
+        {
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, false>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8,
+                               dTiles, n_sym_tiles);
+        }
+        else
+        {
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8,
+                               dTiles, n_sym_tiles);
+        }
     }
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
@@ -1015,6 +1030,20 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* tv = getenv("CSLAM_TUNE_DOWNDATE"))
     {
         b->tune_downdate = atoi(tv);
+    }
+    // Block-lower storage: only 128x128 tiles on/below the tile diagonal of the symmetric P are maintained
+    // (the P-GEMM then writes each tile once).  Needs the persistent symmetric kernel -> f32 default path only.
+    b->lower = (dtype == CSLAM_F32 && b->tune_downdate == 0) ? 1 : 0;
+    if (const char* sv = getenv("CSLAM_STORAGE"))
+    {
+        if (!strcmp(sv, "full"))
+        {
+            b->lower = 0;
+        }
+        else if (!strcmp(sv, "lower") && dtype == CSLAM_F32 && b->tune_downdate == 0)
+        {
+            b->lower = 1;
+        }
     }
     int rc    = b->init();
     if (rc)

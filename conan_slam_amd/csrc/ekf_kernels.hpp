@@ -38,6 +38,15 @@ struct Vec4<float>
     typedef float4 type;
 };
 
+// Block-lower storage (cslam_ekf.hip "lower" mode): P is symmetric and only 128x128 tiles on or below the
+// tile diagonal are maintained; element (i,j) with tile(i) < tile(j) is read from its mirror (j,i).
+template <typename T>
+__device__ inline T p_sym(const T* __restrict__ P, int ldp, int i, int j, int lower)
+{
+    const bool direct = !lower || ((i >> 7) >= (j >> 7));
+    return direct ? P[(size_t)j * ldp + i] : P[(size_t)i * ldp + j];
+}
+
 // EKF.cpp:354-404 for one observation. coef[0..4] = row 0 of H at columns {0,1,2,fx,fx+1},
 // coef[5..9] = row 1; v = innovation (EKF.cpp:117-118, bearing wrapped); fx = 0-based index of the
 // feature's x in the state (= fpos-1 of the reference).
@@ -90,7 +99,7 @@ constexpr int kGatherObs = 8;
 template <typename T>
 __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X, const T* __restrict__ P, int ldp,
                                                           int n, const T* __restrict__ Z, const int* __restrict__ idf,
-                                                          int m, T* __restrict__ PHT, int ldw)
+                                                          int m, T* __restrict__ PHT, int ldw, int lower)
 {
     __shared__ T   s_coef[kGatherObs * 10];
     __shared__ int s_fx[kGatherObs];
@@ -113,8 +122,8 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     {
         const T* c  = &s_coef[oo * 10];
         int      fx = s_fx[oo];
-        T        a  = P[(size_t)fx * ldp + i];
-        T        b  = P[(size_t)(fx + 1) * ldp + i];
+        T        a  = p_sym<T>(P, ldp, i, fx, lower);
+        T        b  = p_sym<T>(P, ldp, i, fx + 1, lower);
         // same summation order as the dense product: columns 0,1,2,fx,fx+1 ascending
         T s0 = p0 * c[0];
         s0 += p1 * c[1];
@@ -616,7 +625,7 @@ __global__ void __launch_bounds__(256, 3) ekf_downdate_f64(double* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(1024) ekf_predict_kernel(T* __restrict__ X, T* __restrict__ P, int ldp, int n, T v,
                                                             T swa, T q00, T q10, T q01, T q11, T wb, T dt,
-                                                            int stripe_w)
+                                                            int stripe_w, int lower)
 {
     __shared__ T s_gv[9];
     __shared__ T s_pvv[9];
@@ -699,7 +708,7 @@ __global__ void __launch_bounds__(1024) ekf_predict_kernel(T* __restrict__ X, T*
     for (int j = tid; j < stripe_w; j += blockDim.x)
     {
         const int c  = 3 + j;
-        T         a0 = P[(size_t)c * ldp + 0], a1 = P[(size_t)c * ldp + 1], a2 = P[(size_t)c * ldp + 2];
+        T         a0 = p_sym<T>(P, ldp, 0, c, lower), a1 = p_sym<T>(P, ldp, 1, c, lower), a2 = p_sym<T>(P, ldp, 2, c, lower);
 #pragma unroll
         for (int r = 0; r < 3; r++)
         {
@@ -727,7 +736,7 @@ __global__ void __launch_bounds__(1024) ekf_predict_kernel(T* __restrict__ X, T*
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(1024) ekf_augment_kernel(T* __restrict__ X, T* __restrict__ P, int ldp, int len, T r,
-                                                            T b, T r00, T r10, T r01, T r11)
+                                                            T b, T r00, T r10, T r01, T r11, int lower)
 {
     __shared__ T s_gv[6];
     const int    tid = threadIdx.x;
@@ -791,7 +800,7 @@ __global__ void __launch_bounds__(1024) ekf_augment_kernel(T* __restrict__ X, T*
     // EKF.cpp:77-78, 83-84: new rows = Gv * P[0:3, 0:len], mirrored into the new columns
     for (int j = tid; j < len; j += blockDim.x)
     {
-        T a0 = P[(size_t)j * ldp + 0], a1 = P[(size_t)j * ldp + 1], a2 = P[(size_t)j * ldp + 2];
+        T a0 = p_sym<T>(P, ldp, 0, j, lower), a1 = p_sym<T>(P, ldp, 1, j, lower), a2 = p_sym<T>(P, ldp, 2, j, lower);
 #pragma unroll
         for (int rr = 0; rr < 2; rr++)
         {
@@ -819,7 +828,7 @@ template <typename T>
 __global__ void __launch_bounds__(1024) ekf_heading_prep_kernel(T* __restrict__ X, const T* __restrict__ P, int ldp,
                                                                  int n, T phi, T R, T* __restrict__ w,
                                                                  T* __restrict__ cp2, T* __restrict__ rrow,
-                                                                 T* __restrict__ scal)
+                                                                 T* __restrict__ scal, int lower)
 {
     __shared__ T s_v, s_si, s_p22, s_omw2;
     const int    tid = threadIdx.x;
@@ -840,7 +849,7 @@ __global__ void __launch_bounds__(1024) ekf_heading_prep_kernel(T* __restrict__ 
         T wi    = pi_ * SI;               // W = PHT*SI
         w[i]    = wi;
         cp2[i]  = (i == 2) ? omw2 * p22 : pi_ - wi * p22; // (C*P)[i,2]; row 2 of C is (1-W[2]) e_2^T
-        rrow[i] = P[(size_t)i * ldp + 2];                 // row 2
+        rrow[i] = p_sym<T>(P, ldp, 2, i, lower);          // row 2 (its mirror, column 2, in lower mode)
         X[i]    = X[i] + wi * V;
     }
     if (tid == 0)
@@ -854,7 +863,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) ekf_heading_apply_kernel(T* __restrict__ P, int ldp, int n,
                                                                  const T* __restrict__ w, const T* __restrict__ cp2,
                                                                  const T* __restrict__ rrow,
-                                                                 const T* __restrict__ scal, T tiny)
+                                                                 const T* __restrict__ scal, T tiny, int lower)
 {
     // block: 256 rows x 16 columns
     const int i  = blockIdx.x * 256 + threadIdx.x;
@@ -862,6 +871,10 @@ __global__ void __launch_bounds__(256) ekf_heading_apply_kernel(T* __restrict__ 
     if (i >= n)
     {
         return;
+    }
+    if (lower && ((blockIdx.x * 256 + 255) >> 7) < (j0 >> 7))
+    {
+        return; // every element of this block lies in tiles above the diagonal: not maintained
     }
     const T wi = w[i], ci2 = cp2[i];
     const T R = scal[0], omw2 = scal[1];

@@ -316,25 +316,25 @@ __global__ void __launch_bounds__(64) ekf_gain_mfma_f32(const float* __restrict_
     f32x16     acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
     float      xs0 = 0.f, xs1 = 0.f, xs2 = 0.f, xs3 = 0.f;
     const float* pb = PHT + row0 + 4 * lj;
-    for (int qb = 0; qb < k; qb += 16)
+    constexpr int NP = 16; // k-pairs per trip: all their loads are issued before the first MFMA
+    for (int qb = 0; qb < k; qb += 2 * NP)
     {
-        // 8 k-pairs per trip, all 16 loads issued before the first MFMA; pairs beyond k contribute zeros
-        float4 b[8];
-        float  g[8], uq[8];
+        float4 b[NP];
+        float  g[NP], uq[NP];
 #pragma unroll
-        for (int t = 0; t < 8; t++)
+        for (int t = 0; t < NP; t++)
         {
             const int q  = qb + 2 * t + lh;
-            const int qc = (q < k) ? q : (k - 1);
+            const int qc = (q < k) ? q : (k - 1); // clamped: pairs beyond k contribute zeros via the selects below
             b[t]         = *reinterpret_cast<const float4*>(pb + (size_t)qc * ldw);
             g[t]         = Gt[(size_t)qc * k + cc];
             uq[t]        = u[qc];
         }
 #pragma unroll
-        for (int t = 0; t < 8; t++)
+        for (int t = 0; t < NP; t++)
         {
-            const int  q  = qb + 2 * t + lh;
-            const bool ok = q < k;
+            const int   q  = qb + 2 * t + lh;
+            const bool  ok = q < k;
             const float gg = (ok && cok) ? g[t] : 0.f;
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].y, acc1, 0, 0, 0);
@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 //     floats per wave-instruction, lane-linear LDS image; k8 = round_up(k, 8), columns [k, k8) of W1 are zero.
 // Register plan per lane: 64 accumulators + 2 x 64 P-tile values; pinned to two waves per SIMD.
 // ------------------------------------------------------------------------------------------------
-template <int KC, bool NT>
+template <int KC, bool NT, bool MIRROR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
                       const int2* __restrict__ tile_list, int ntiles)
@@ -979,7 +979,7 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
                 *reinterpret_cast<f32x4*>(dst) = pv[r];
             }
         }
-        if (cur.x != cur.y) // mirror tile (tj, ti)
+        if (MIRROR && cur.x != cur.y) // mirror tile (tj, ti); skipped under block-lower storage
         {
             float* mbase = P + (size_t)(row0 + 4 * lj) * ldp + col0 + wave * 32 + 4 * lh;
 #pragma unroll
@@ -1029,12 +1029,46 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Block-lower storage -> full symmetric matrix (used by get_state): every tile above the tile diagonal is
+// filled with the transpose of its mirror.  32x32 sub-tiles through LDS so both sides are coalesced.
+// grid = (ceil(n/32), ceil(n/32)); blocks not strictly above the 128-tile diagonal exit.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_mirror_upper_kernel(T* __restrict__ P, int ldp, int n)
+{
+    __shared__ T tile[32][33];
+    const int    bi = blockIdx.x * 32; // destination rows (upper part: small row index)
+    const int    bj = blockIdx.y * 32; // destination columns
+    if ((bi >> 7) >= (bj >> 7))
+    {
+        return;
+    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    for (int r = ty; r < 32; r += 8)
+    {
+        // source element (bj + tx, bi + r): column bi + r, rows bj..bj+31 (coalesced along tx)
+        const int si = bj + tx, sj = bi + r;
+        tile[r][tx] = (si < n && sj < n) ? P[(size_t)sj * ldp + si] : (T)0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+    {
+        // destination element (bi + tx, bj + c) = source (bj + c, bi + tx) = tile[tx][c]
+        const int di = bi + tx, dj = bj + c;
+        if (di < n && dj < n)
+        {
+            P[(size_t)dj * ldp + di] = tile[tx][c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6 split: (a) the cross-covariance stripe on many CUs (reads the old heading, writes only the stripe),
 // (b) a one-wave kernel for Pvv and the pose.  Stream order makes (b) see the old pose as (a) did.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) ekf_predict_stripe_kernel(const T* __restrict__ X, T* __restrict__ P, int ldp, T v,
-                                                                  T swa, T dt, int stripe_w)
+                                                                  T swa, T dt, int stripe_w, int lower)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= stripe_w)
@@ -1045,7 +1079,7 @@ __global__ void __launch_bounds__(256) ekf_predict_stripe_kernel(const T* __rest
     const T g02 = -v * dt * dsin(swa + phi); // Gv = [[1,0,g02],[0,1,g12],[0,0,1]]  (EKF.cpp:419-428)
     const T g12 = v * dt * dcos(swa + phi);
     const int c  = 3 + j;
-    const T   a0 = P[(size_t)c * ldp + 0], a1 = P[(size_t)c * ldp + 1], a2 = P[(size_t)c * ldp + 2];
+    const T   a0 = p_sym<T>(P, ldp, 0, c, lower), a1 = p_sym<T>(P, ldp, 1, c, lower), a2 = p_sym<T>(P, ldp, 2, c, lower);
     // rows of Gv * stripe in the dense summation order (zeros of Gv included)
     T o0 = (T)1 * a0;
     o0 += (T)0 * a1;
