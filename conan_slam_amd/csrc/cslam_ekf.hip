@@ -38,6 +38,7 @@ struct EkfBase
     int         n        = 3;
     int         sync_mode = 1;
     int         tune_downdate = 0; // experiment selector (env CSLAM_TUNE_DOWNDATE), 0 = shipped default
+    int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 parallel LDS kernel, 1 one-wave register kernel, 2 general
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     hipStream_t stream   = nullptr;
 
@@ -183,6 +184,13 @@ struct Ekf : EkfBase
         // allow the factor kernel its large dynamic LDS
         CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_kernel<T>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_par_kernel<T, 64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (sizeof(T) == 4)
+        {
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_par_kernel<T, 128>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
         rc = ensure_k(64);
         if (rc)
         {
@@ -483,9 +491,36 @@ struct Ekf : EkfBase
         a.textbook = (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1;
         a.lds_S    = 1;
         a.lds_G    = 1;
-        if (k <= 64)
         {
-            // register-resident factorisation by one wave (ekf_kernels_fast.hpp)
+            // workgroup-parallel factorisation (ekf_kernels_fast.hpp); K = 128 only fits LDS in f32
+            const int    kmaxp = (sizeof(T) == 4) ? 128 : 64;
+            const size_t elt   = sizeof(T);
+            auto lds_par = [&](int K) { return (size_t)(2 * K * (K + 1) + (K / 2) * 10 + 2 * K + 2) * elt + (K / 2 + 2) * 4 + 32; };
+            if (k <= kmaxp && tune_factor == 0)
+            {
+                if (k <= 16)
+                {
+                    hipLaunchKernelGGL((ekf_factor_par_kernel<T, 16>), dim3(1), dim3(64), lds_par(16), stream, a, dU);
+                }
+                else if (k <= 32)
+                {
+                    hipLaunchKernelGGL((ekf_factor_par_kernel<T, 32>), dim3(1), dim3(128), lds_par(32), stream, a, dU);
+                }
+                else if (k <= 64)
+                {
+                    hipLaunchKernelGGL((ekf_factor_par_kernel<T, 64>), dim3(1), dim3(256), lds_par(64), stream, a, dU);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((ekf_factor_par_kernel<T, 128>), dim3(1), dim3(512), lds_par(128), stream, a, dU);
+                }
+                CSLAM_HIP_TRY(hipGetLastError());
+                return CSLAM_OK;
+            }
+        }
+        if (k <= 64 && tune_factor != 2)
+        {
+            // register-resident factorisation by one wave (kept for A/B: CSLAM_TUNE_FACTOR=1)
             if (k <= 4)
             {
                 hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
@@ -920,11 +955,11 @@ int Ekf<float>::launch_downdate(int k)
 template <>
 bool Ekf<float>::launch_gain_fast(int k, int n_pad)
 {
-    if (k > 64)
+    if (k > 128 || (k > 64 && tune_factor != 0))
     {
-        return false; // du is produced by the register-resident factor kernel only
+        return false; // du is produced by the tuned factor kernels only
     }
-    hipLaunchKernelGGL(ekf_gain_mfma_f32, dim3(n_pad / kTile, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n, k, dGt, dU,
+    hipLaunchKernelGGL(ekf_gain_mfma_f32, dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n, k, dGt, dU,
                        dW1, dX);
     return true;
 }
@@ -1027,6 +1062,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     b->ncap   = 3 + 2 * max_landmarks;
     b->ldp    = round_up(b->ncap, kTile);
     b->n      = 3;
+    if (const char* tf = getenv("CSLAM_TUNE_FACTOR"))
+    {
+        b->tune_factor = atoi(tf);
+    }
     if (const char* tv = getenv("CSLAM_TUNE_DOWNDATE"))
     {
         b->tune_downdate = atoi(tv);

@@ -292,41 +292,306 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2+K3, workgroup-parallel form for k <= K (K = 16, 32, 64, 128): threads = 4*K, thread = (row r, part p).
+// The matrix stays in LDS (leading dimension K+1).  Every length-j dot product of the column-by-column
+// Cholesky and of the forward substitution is split over the 4 lanes of a row (q = p, p+4, ...) and combined
+// with two __shfl_xor, so the serial chain per column is ~j/4 FMAs instead of j.  The Cholesky needs two
+// barriers per column (pivot, column publish); the inverse needs none (L is read-only by then, each row of
+// lanes owns one column of inv(L) in registers).  Same outputs as ekf_factor_small_kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ void __launch_bounds__((4 * K < 64) ? 64 : 4 * K) ekf_factor_par_kernel(FactorArgs<T> a, T* __restrict__ du)
+{
+    constexpr int NT = (4 * K < 64) ? 64 : 4 * K;
+    constexpr int LD = K + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T*   S    = reinterpret_cast<T*>(smem_raw); // K*LD : S, then L in place
+    T*   G    = S + K * LD;                     // K*LD : inv(L) / G
+    T*   coef = G + K * LD;                     // (K/2)*10
+    T*   V    = coef + (K / 2) * 10;            // K
+    T*   tvec = V + K;                          // K
+    T*   pivb = tvec + K;                       // 1 (+1 pad)
+    int* fxs  = reinterpret_cast<int*>(pivb + 2); // K/2
+    int* sflg = fxs + K / 2;                    // 2
+    const int k   = 2 * a.m;
+    const int tid = threadIdx.x;
+
+    if (tid == 0)
+    {
+        sflg[0] = 0;
+        sflg[1] = 0;
+    }
+    if (tid < K)
+    {
+        V[tid] = (T)0;
+    }
+    __syncthreads();
+    for (int o = tid; o < a.m; o += NT)
+    {
+        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    __syncthreads();
+    // S = H*PHT + RR (slam.h:244), identity padding; all loads of a thread issued before the sums
+    {
+        constexpr int NE = (K * K + NT - 1) / NT;
+        T             ph[NE][5];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int  e  = tid + it * NT;
+            const int  r  = e & (K - 1);
+            const int  c  = e / K;
+            const bool in = (e < K * K) && (r < k) && (c < k);
+            const int  rc = in ? r : 0, cc = in ? c : 0;
+            const int  fx = fxs[rc >> 1];
+            const T*   p  = a.PHT + (size_t)cc * a.ldw;
+            ph[it][0]     = p[0];
+            ph[it][1]     = p[1];
+            ph[it][2]     = p[2];
+            ph[it][3]     = p[fx];
+            ph[it][4]     = p[fx + 1];
+        }
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * NT;
+            if (e < K * K)
+            {
+                const int r = e & (K - 1);
+                const int c = e / K;
+                T         v;
+                if (r < k && c < k)
+                {
+                    const int ob = r >> 1, ra = r & 1;
+                    const T*  cf = &coef[ob * 10 + ra * 5];
+                    T         sm = cf[0] * ph[it][0];
+                    sm += cf[1] * ph[it][1];
+                    sm += cf[2] * ph[it][2];
+                    sm += cf[3] * ph[it][3];
+                    sm += cf[4] * ph[it][4];
+                    v = sm + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0);
+                }
+                else
+                {
+                    v = (r == c) ? (T)1 : (T)0;
+                }
+                S[r + c * LD] = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < K * K; e += NT) // makeSymmetric (slam.h:776-779)
+    {
+        const int r = e & (K - 1);
+        const int c = e / K;
+        if (r > c)
+        {
+            T v           = (S[r + c * LD] + S[c + r * LD]) * (T)0.5;
+            S[r + c * LD] = v;
+            S[c + r * LD] = v;
+        }
+        else if (r == c)
+        {
+            T d           = S[r + c * LD];
+            S[r + c * LD] = (d + d) * (T)0.5;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < K * K; e += NT)
+    {
+        const int r = e & (K - 1), c = e / K;
+        if (r < k && c < k)
+        {
+            a.dS[r + c * k] = S[r + c * LD];
+        }
+    }
+    __syncthreads();
+
+    // ---- lower Cholesky, column by column; thread = (row r, part p); a pivot <= 0 is the LLT failure (slam.h:421)
+    const int  r      = tid >> 2;
+    const int  part   = tid & 3;
+    const bool rowok  = (r < K);
+    bool       failed = false;
+    for (int j = 0; j < K; j++)
+    {
+        T dot = (T)0;
+        if (rowok)
+        {
+            for (int q = part; q < j; q += 4)
+            {
+                dot += S[r + q * LD] * S[j + q * LD];
+            }
+        }
+        dot += __shfl_xor(dot, 1);
+        dot += __shfl_xor(dot, 2);
+        const T sv = rowok ? (S[r + j * LD] - dot) : (T)0;
+        if (rowok && part == 0 && r == j)
+        {
+            pivb[0] = sv;
+        }
+        __syncthreads();
+        const T d = pivb[0];
+        if (d <= (T)0)
+        {
+            failed = true; // uniform: every thread read the same pivot
+            break;
+        }
+        const T sj = dsqrt(d);
+        if (rowok && part == 0 && r >= j)
+        {
+            S[r + j * LD] = (r == j) ? sj : sv / sj;
+        }
+        __syncthreads();
+    }
+    // ---- inv(L) by forward substitution: (row-of-lanes c, part p) owns x[q], q = p + 4i, of column c
+    bool bad = false;
+    if (!failed)
+    {
+        const int c = r;
+        T         x[K / 4 + 1];
+#pragma unroll
+        for (int i = 0; i < K / 4 + 1; i++)
+        {
+            x[i] = (T)0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < K; rr++)
+        {
+            T sum = (T)0;
+#pragma unroll
+            for (int i = 0; i < (rr + 3) / 4; i++) // q = part + 4i < rr for the parts that have one; others add 0*...
+            {
+                const int q = part + 4 * i;
+                if (q < rr)
+                {
+                    sum += S[rr + q * LD] * x[i];
+                }
+            }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            const T xr = (((c == rr) ? (T)1 : (T)0) - sum) / S[rr + rr * LD];
+            if (part == (rr & 3))
+            {
+                x[rr >> 2] = xr;
+            }
+            if (rowok && c < k && part == (rr & 3))
+            {
+                bad = bad || !dfinite(xr);
+            }
+        }
+        if (rowok)
+        {
+#pragma unroll
+            for (int i = 0; i < K / 4; i++)
+            {
+                G[(part + 4 * i) + c * LD] = x[i]; // inv(L)[q][c]
+            }
+        }
+    }
+    if (bad)
+    {
+        atomicOr(&sflg[1], 1);
+    }
+    __syncthreads();
+    const bool zero = failed || (sflg[1] != 0);
+    // outputs in the final orientation: REF_EXACT G = inv(L); TEXTBOOK G = inv(L)^T (quirk #1)
+    for (int e = tid; e < K * K; e += NT)
+    {
+        const int rr = e & (K - 1), cc = e / K;
+        if (rr < k && cc < k)
+        {
+            const T g = zero ? (T)0 : (a.textbook ? G[cc + rr * LD] : G[rr + cc * LD]);
+            a.dG[rr + cc * k]  = g;
+            a.dGt[cc + rr * k] = g;
+        }
+    }
+    // t = G^T V and u = G t, 4 lanes per output
+    {
+        const int o = tid >> 2;
+        T         s1 = (T)0;
+        if (o < K && !zero)
+        {
+            for (int q = part; q < K; q += 4)
+            {
+                const T g = a.textbook ? G[o + q * LD] : G[q + o * LD]; // G[q][o]
+                s1 += g * V[q];
+            }
+        }
+        s1 += __shfl_xor(s1, 1);
+        s1 += __shfl_xor(s1, 2);
+        if (part == 0 && o < K)
+        {
+            if (o < k)
+            {
+                a.dt[o] = s1;
+            }
+            tvec[o] = (o < k) ? s1 : (T)0;
+        }
+        __syncthreads();
+        T s2 = (T)0;
+        if (o < K && !zero)
+        {
+            for (int q = part; q < K; q += 4)
+            {
+                const T g = a.textbook ? G[q + o * LD] : G[o + q * LD]; // G[o][q]
+                s2 += g * tvec[q];
+            }
+        }
+        s2 += __shfl_xor(s2, 1);
+        s2 += __shfl_xor(s2, 2);
+        if (part == 0 && o < k)
+        {
+            du[o] = s2;
+        }
+    }
+    if (tid == 0)
+    {
+        const int code = (failed ? kFlagLltFailed : 0) | ((!failed && sflg[1]) ? kFlagZeroed : 0);
+        a.flags[1]     = code;
+        if (code)
+        {
+            atomicOr(&a.flags[0], code);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4 (f32) on MFMA: W1 = PHT * G (slam.h:257), X += PHT * u with u = G*(G^T V) (slam.h:258-259 regrouped).
-// Tile = 128 rows x 32 columns per wave, rows interleaved 4-per-lane exactly as in the downdate so that
-// PHT is read and W1 written with 16-byte accesses.  D[i][j]: i <-> output column, j <-> row slot.
+// Tile = 32 rows x 32 columns per wave.  D[i][j]: i <-> output column, j <-> row (contiguous across lanes).
 //   A[i = lane&31][kq = lane>>5] = G[q0+kq][c0+i]   (read from Gt, contiguous across lanes)
-//   B[kq][j]                     = PHT[row0 + 4j + b][q0+kq]
+//   B[kq][j]                     = PHT[row0 + j][q0+kq]
 // PHT rows >= n are zero (never written), so W1's padding rows come out zero as the downdate needs.
-// grid = (n_pad/128, ceil(k/32)) single-wave workgroups; column tile 0 also updates X.
+// grid = (n_pad/32, ceil(k/32)) single-wave workgroups; column tile 0 also updates X.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) ekf_gain_mfma_f32(const float* __restrict__ PHT, int ldw, int n, int k,
                                                          const float* __restrict__ Gt, const float* __restrict__ u,
                                                          float* __restrict__ W1, float* __restrict__ X)
 {
-    // one wave per workgroup: grid = (n_pad/128 row tiles, ceil(k/32) column tiles)
+    // one wave per workgroup, one 32x32 MFMA tile per wave: grid = (n_pad/32 row tiles, ceil(k/32) column tiles).
+    // Small tiles on purpose: the kernel is a latency chain (load -> MFMA -> store), so it wants many waves.
     const int  lane = threadIdx.x;
     const int  lj   = lane & 31;
     const int  lh   = lane >> 5;
-    const int  row0 = blockIdx.x * 128;
+    const int  row0 = blockIdx.x * 32;
     const int  c0   = blockIdx.y * 32;
     const bool cok  = (c0 + lj) < k;
     const int  cc   = cok ? (c0 + lj) : (k - 1); // clamped: loads are unconditional, the VALUE is selected
     const bool dox  = (blockIdx.y == 0);
-    f32x16     acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-    float      xs0 = 0.f, xs1 = 0.f, xs2 = 0.f, xs3 = 0.f;
-    const float* pb = PHT + row0 + 4 * lj;
-    constexpr int NP = 16; // k-pairs per trip: all their loads are issued before the first MFMA
+    f32x16     acc  = {0};
+    float      xs   = 0.f;
+    const float* pb = PHT + row0 + lj;
+    constexpr int NP = 32; // k-pairs per trip: every load of the trip is issued before its first MFMA
     for (int qb = 0; qb < k; qb += 2 * NP)
     {
-        float4 b[NP];
-        float  g[NP], uq[NP];
+        float b[NP], g[NP], uq[NP];
 #pragma unroll
         for (int t = 0; t < NP; t++)
         {
             const int q  = qb + 2 * t + lh;
-            const int qc = (q < k) ? q : (k - 1); // clamped: pairs beyond k contribute zeros via the selects below
-            b[t]         = *reinterpret_cast<const float4*>(pb + (size_t)qc * ldw);
+            const int qc = (q < k) ? q : (k - 1);
+            b[t]         = pb[(size_t)qc * ldw];
             g[t]         = Gt[(size_t)qc * k + cc];
             uq[t]        = u[qc];
         }
@@ -336,40 +601,28 @@ __global__ void __launch_bounds__(64) ekf_gain_mfma_f32(const float* __restrict_
             const int   q  = qb + 2 * t + lh;
             const bool  ok = q < k;
             const float gg = (ok && cok) ? g[t] : 0.f;
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].y, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].z, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, b[t].w, acc3, 0, 0, 0);
-            const float uu = ok ? uq[t] : 0.f;
-            xs0 += b[t].x * uu;
-            xs1 += b[t].y * uu;
-            xs2 += b[t].z * uu;
-            xs3 += b[t].w * uu;
+            const float bb = ok ? b[t] : 0.f;
+            acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, bb, acc, 0, 0, 0);
+            xs += bb * uq[t];
         }
     }
+    const int k8 = (k + 7) & ~7; // columns [k, k8) are written as zeros for the downdate's k-blocking
 #pragma unroll
     for (int r = 0; r < 16; r++)
     {
         const int col = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (col < ((k + 7) & ~7)) // columns [k, round_up(k,8)) are written as zeros for the downdate
+        if (col < k8)
         {
-            float4 v = (col < k) ? make_float4(acc0[r], acc1[r], acc2[r], acc3[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(W1 + (size_t)col * ldw + row0 + 4 * lj) = v;
+            W1[(size_t)col * ldw + row0 + lj] = (col < k) ? acc[r] : 0.f;
         }
     }
     if (dox)
     {
-        xs0 += __shfl_xor(xs0, 32);
-        xs1 += __shfl_xor(xs1, 32);
-        xs2 += __shfl_xor(xs2, 32);
-        xs3 += __shfl_xor(xs3, 32);
-        if (lh == 0)
+        xs += __shfl_xor(xs, 32);
+        const int r = row0 + lj;
+        if (lh == 0 && r < n)
         {
-            const int r = row0 + 4 * lj;
-            if (r + 0 < n) X[r + 0] += xs0;
-            if (r + 1 < n) X[r + 1] += xs1;
-            if (r + 2 < n) X[r + 2] += xs2;
-            if (r + 3 < n) X[r + 3] += xs3;
+            X[r] += xs;
         }
     }
 }
