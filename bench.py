@@ -47,6 +47,8 @@ def parse_args():
                     help="gain algebra; identical cost. REF_EXACT on this synthetic map turns every update after the "
                          "first into the reference's LLT-failure no-op (DESIGN.md), so the timed loop uses TEXTBOOK")
     ap.add_argument("--sequential", action="store_true", help="batch=false (EKF.cpp:457-479)")
+    ap.add_argument("--defer", type=int, default=0,
+                    help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = every update at once)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-profile", action="store_true", help="extra untimed pass with events around every stage")
@@ -120,6 +122,8 @@ def main():
     quirks = Q_TEXTBOOK if args.quirks == "textbook" else Q_REF_EXACT
     eng = EKF(args.landmarks, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
     eng.set_state(w.X0, w.P0)
+    if args.defer > 0:
+        eng.set_deferred(args.defer)
     w.P0 = None  # free 400 MB of host memory
 
     # inputs of every step, generated up front and made resident in HBM
@@ -156,6 +160,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.warmup, total_steps):
         step(t)
+    eng.flush()  # deferred mode: the last pending panels are applied inside the timed region
     eng.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -186,9 +191,11 @@ def main():
 
     dd_ms, dd_cnt = stages["downdate"]
     dd_s = (dd_ms / max(dd_cnt, 1)) * 1e-3
+    # columns one P-GEMM launch applies: k, or (deferred / sequential) the pending columns of several updates
+    k_launch = (k if batch else 2 * m) * args.steps / max(dd_cnt, 1) if args.defer > 0 else (k if batch else 2 * m)
     # algorithmic bytes of one downdate launch: P read once + written once, W1 read once
-    dd_bytes = 2.0 * n * n * esize + 1.0 * n * k * esize
-    dd_flops = 2.0 * n * n * k
+    dd_bytes = 2.0 * n * n * esize + 1.0 * n * k_launch * esize
+    dd_flops = 2.0 * n * n * k_launch
     achieved = dd_bytes / dd_s / 1e9 if dd_s > 0 else None
     out = {
         "metric": "ekf_update_steps_per_sec",
@@ -211,6 +218,7 @@ def main():
             "obs_per_update": m,
             "k": k,
             "gain_algebra": args.quirks,
+            "deferred_columns": args.defer,
             "parallelism": f"replicas x{world} (no collective)",
             "baseline_config": "BASELINE.json configs[2]" if (args.landmarks, args.dtype) == (5000, "f32") else "custom",
         },
@@ -225,6 +233,7 @@ def main():
             "algorithmic_bytes_per_launch": dd_bytes,
             "launch_us": dd_s * 1e6,
             "launches_timed": dd_cnt,
+            "k_per_launch": k_launch,
             "mfma_tflops_issued": dd_flops / dd_s / 1e12 if dd_s > 0 else None,
             "mfma_frac_of_peak": (dd_flops / dd_s / 1e12 / MFMA_PEAK_TF[args.dtype]) if dd_s > 0 else None,
         },

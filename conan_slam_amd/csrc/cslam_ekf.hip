@@ -38,7 +38,8 @@ struct EkfBase
     int         n        = 3;
     int         sync_mode = 1;
     int         tune_downdate = 0; // experiment selector (env CSLAM_TUNE_DOWNDATE), 0 = shipped default
-    int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 parallel LDS kernel, 1 one-wave register kernel, 2 general
+    int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
+    int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (readlane one-wave for k<=64, workgroup-parallel to 128), 2 general, 3 workgroup-parallel always, 4 LDS-broadcast one-wave
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     hipStream_t stream   = nullptr;
 
@@ -55,6 +56,8 @@ struct EkfBase
     virtual int set_profiling(int on)                                                          = 0;
     virtual int get_stage_times(double* ms, int* launches)                                     = 0;
     virtual int debug_last_update(void* PHT, void* S, void* G, void* W1, void* V, int* k)      = 0;
+    virtual int set_deferred(int max_cols)                                                     = 0;
+    virtual int do_flush()                                                                     = 0;
 };
 
 template <typename T>
@@ -65,7 +68,12 @@ struct Ekf : EkfBase
     // update workspace
     int  kcap  = 0;
     T*   dPHT  = nullptr;
-    T*   dW1   = nullptr;
+    T*   dW1   = nullptr; // pending W1 panels, ldp x wcap (the current update's W1 is the slot at column kp)
+    T*   dY    = nullptr; // Y = H*Wp (kcap x wcap), correction of PHT under pending panels
+    int  wcap  = 0;       // columns of dW1
+    int  kp    = 0;       // pending columns (downdates not applied to P yet)
+    int  defer_max = 0;   // > 0: keep up to this many pending columns across calls (cslam_ekf_set_deferred)
+    int  slot_col  = 0;   // first column of the last update's W1
     T*   dS    = nullptr;
     T*   dG    = nullptr;
     T*   dGt   = nullptr;
@@ -93,6 +101,7 @@ struct Ekf : EkfBase
     // status
     int sticky_host = 0; // flags raised by host-side decisions (FALLBACK/SKIPPED)
     int last_k      = 0;
+    int kp_call_limit = 0; // pending columns a sequential update() may accumulate within the call
     // profiling
     int                     profiling = 0;
     std::vector<hipEvent_t> ev_pool;
@@ -121,6 +130,8 @@ struct Ekf : EkfBase
         free_workspace();
         (void)hipFree(dFlags);
         (void)hipFree(dHead);
+        (void)hipFree(dW1);
+        (void)hipFree(dY);
         (void)hipFree(dTiles);
         (void)hipFree(dStage);
         if (hStage)
@@ -140,7 +151,6 @@ struct Ekf : EkfBase
     void free_workspace()
     {
         (void)hipFree(dPHT);
-        (void)hipFree(dW1);
         (void)hipFree(dS);
         (void)hipFree(dG);
         (void)hipFree(dGt);
@@ -149,7 +159,7 @@ struct Ekf : EkfBase
         (void)hipFree(dU);
         (void)hipFree(dScrS);
         (void)hipFree(dScrG);
-        dPHT = dW1 = dS = dG = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
+        dPHT = dS = dG = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
     }
 
     int use_device() { CSLAM_HIP_TRY(hipSetDevice(device)); return CSLAM_OK; }
@@ -196,6 +206,11 @@ struct Ekf : EkfBase
         {
             return rc;
         }
+        rc = ensure_w(64);
+        if (rc)
+        {
+            return rc;
+        }
         rc = ensure_m(64);
         if (rc)
         {
@@ -218,7 +233,6 @@ struct Ekf : EkfBase
         size_t pan = (size_t)ldp * newk * sizeof(T);
         size_t kk  = (size_t)newk * (newk + 1) * sizeof(T);
         CSLAM_HIP_TRY(hipMalloc(&dPHT, pan));
-        CSLAM_HIP_TRY(hipMalloc(&dW1, pan));
         CSLAM_HIP_TRY(hipMalloc(&dS, kk));
         CSLAM_HIP_TRY(hipMalloc(&dG, kk));
         CSLAM_HIP_TRY(hipMalloc(&dGt, kk));
@@ -228,8 +242,69 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMalloc(&dt_, (size_t)newk * sizeof(T)));
         CSLAM_HIP_TRY(hipMalloc(&dU, (size_t)newk * sizeof(T)));
         CSLAM_HIP_TRY(hipMemsetAsync(dPHT, 0, pan, stream));
-        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, pan, stream));
         kcap = newk;
+        if (dY)
+        {
+            (void)hipFree(dY);
+            dY = nullptr;
+        }
+        if (wcap > 0)
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dY, (size_t)kcap * wcap * sizeof(T)));
+        }
+        return CSLAM_OK;
+    }
+
+    // room for `cols` pending columns; flushes first when the buffer has to move
+    int ensure_w(int cols)
+    {
+        cols = round_up(cols, 8);
+        if (cols <= wcap)
+        {
+            return CSLAM_OK;
+        }
+        int rc = flush();
+        if (rc)
+        {
+            return rc;
+        }
+        int neww = round_up(std::max(cols, 2 * wcap), 8);
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(dW1);
+        (void)hipFree(dY);
+        dW1 = nullptr;
+        dY  = nullptr;
+        CSLAM_HIP_TRY(hipMalloc(&dW1, (size_t)ldp * neww * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dY, (size_t)std::max(kcap, 8) * neww * sizeof(T)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, (size_t)ldp * neww * sizeof(T), stream));
+        wcap = neww;
+        return CSLAM_OK;
+    }
+
+    // apply every pending panel to P in ONE P-GEMM with k = kp (slam.h:260 is linear in the panels)
+    int flush()
+    {
+        if (kp == 0)
+        {
+            return CSLAM_OK;
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const int kp8 = round_up(kp, 8);
+        if (kp8 > kp) // the LDS-DMA P-GEMM reads W1 in blocks of 8 columns
+        {
+            CSLAM_HIP_TRY(hipMemset2DAsync(dW1 + (size_t)kp * ldp, (size_t)ldp * sizeof(T), 0,
+                                           (size_t)round_up(n, kTile) * sizeof(T), (size_t)(kp8 - kp), stream));
+        }
+        if ((rc = prof_begin(CSLAM_STAGE_DOWNDATE)) || (rc = launch_downdate(dW1, kp)) ||
+            (rc = prof_end(CSLAM_STAGE_DOWNDATE)))
+        {
+            return rc;
+        }
+        kp = 0;
         return CSLAM_OK;
     }
 
@@ -302,8 +377,9 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMemcpy2DAsync(dP, (size_t)ldp * sizeof(T), P, (size_t)ldph * sizeof(T), (size_t)nn * sizeof(T),
                                        (size_t)nn, hipMemcpyHostToDevice, stream));
         // panels: rows beyond the new n must read as zero (the tuned gain kernel relies on it)
+        kp = 0; // a new state discards updates that were never applied
         CSLAM_HIP_TRY(hipMemsetAsync(dPHT, 0, (size_t)ldp * kcap * sizeof(T), stream));
-        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, (size_t)ldp * kcap * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, (size_t)ldp * wcap * sizeof(T), stream));
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         n = nn;
         return CSLAM_OK;
@@ -317,6 +393,10 @@ struct Ekf : EkfBase
         }
         int rc = use_device();
         if (rc)
+        {
+            return rc;
+        }
+        if (P && (rc = flush()))
         {
             return rc;
         }
@@ -356,6 +436,10 @@ struct Ekf : EkfBase
         }
         int rc = use_device();
         if (rc)
+        {
+            return rc;
+        }
+        if ((rc = flush()))
         {
             return rc;
         }
@@ -451,6 +535,13 @@ struct Ekf : EkfBase
         {
             w = (quirks & CSLAM_Q_PREDICT_NM4) ? (n - 4) : (n - 3);
         }
+        if (kp > 0) // pose rows of the pending panels move with the pose (before anything changes X[2])
+        {
+            const int fix_last = (n > 3 && (quirks & CSLAM_Q_PREDICT_NM4)) ? 1 : 0;
+            hipLaunchKernelGGL(ekf_pending_predict_kernel<T>, dim3(1), dim3(256), 0, stream, dX, dP, ldp, n, (T)v, (T)swa,
+                               (T)dt, dW1, ldp, kp, fix_last);
+            CSLAM_HIP_TRY(hipGetLastError());
+        }
         if (w > 0)
         {
             hipLaunchKernelGGL(ekf_predict_stripe_kernel<T>, dim3((w + 255) / 256), dim3(256), 0, stream, dX, dP, ldp,
@@ -496,7 +587,7 @@ struct Ekf : EkfBase
             const int    kmaxp = (sizeof(T) == 4) ? 128 : 64;
             const size_t elt   = sizeof(T);
             auto lds_par = [&](int K) { return (size_t)(2 * K * (K + 1) + (K / 2) * 10 + 2 * K + 2) * elt + (K / 2 + 2) * 4 + 32; };
-            if (k <= kmaxp && tune_factor == 0)
+            if (k <= kmaxp && (tune_factor == 3 || (tune_factor == 0 && k > 64)))
             {
                 if (k <= 16)
                 {
@@ -518,9 +609,31 @@ struct Ekf : EkfBase
                 return CSLAM_OK;
             }
         }
+        if (k <= 64 && tune_factor == 4)
+        {
+            // one-wave factorisation with LDS broadcasts (experiment: hipcc 7.2 spills it at K = 64)
+            if (k <= 4)
+            {
+                hipLaunchKernelGGL((ekf_factor_small2_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
+            }
+            else if (k <= 16)
+            {
+                hipLaunchKernelGGL((ekf_factor_small2_kernel<T, 16>), dim3(1), dim3(256), 0, stream, a, dU);
+            }
+            else if (k <= 32)
+            {
+                hipLaunchKernelGGL((ekf_factor_small2_kernel<T, 32>), dim3(1), dim3(256), 0, stream, a, dU);
+            }
+            else
+            {
+                hipLaunchKernelGGL((ekf_factor_small2_kernel<T, 64>), dim3(1), dim3(256), 0, stream, a, dU);
+            }
+            CSLAM_HIP_TRY(hipGetLastError());
+            return CSLAM_OK;
+        }
         if (k <= 64 && tune_factor != 2)
         {
-            // register-resident factorisation by one wave (kept for A/B: CSLAM_TUNE_FACTOR=1)
+            // register-resident factorisation with v_readlane broadcasts (A/B: CSLAM_TUNE_FACTOR=1)
             if (k <= 4)
             {
                 hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
@@ -550,32 +663,29 @@ struct Ekf : EkfBase
         return CSLAM_OK;
     }
 
+    // W1 of this update goes to the pending slot starting at column slot_col
     int launch_gain(int k)
     {
         const int n_pad = round_up(n, kTile);
-        if (launch_gain_fast(k, n_pad))
+        T*        slot  = dW1 + (size_t)slot_col * ldp;
+        if (launch_gain_fast(k, n_pad, slot))
         {
             CSLAM_HIP_TRY(hipGetLastError());
             return CSLAM_OK;
         }
         hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
-                           dW1, dX);
+                           slot, dX);
         CSLAM_HIP_TRY(hipGetLastError());
-        const int k8 = round_up(k, 8);
-        if (k8 > k) // the LDS-DMA downdate reads W1 in blocks of 8 columns
-        {
-            CSLAM_HIP_TRY(hipMemset2DAsync(dW1 + (size_t)k * ldp, (size_t)ldp * sizeof(T), 0, (size_t)n_pad * sizeof(T),
-                                           (size_t)(k8 - k), stream));
-        }
         return CSLAM_OK;
     }
 
-    int  launch_downdate(int k);
+    int  launch_downdate(const T* W, int k);
     int  ensure_tile_list(int tiles);
-    bool launch_gain_fast(int k, int n_pad); // MFMA gain (f32, k <= 64 where du is available)
+    bool launch_gain_fast(int k, int n_pad, T* slot); // MFMA gain (f32, k <= 128 where du is available)
 
-    // one batch of m observations with device-resident Z / idf (slam.h:235-266 via EKF.cpp:93-129)
-    int batch_on_device(const T* dZ, const int* dIdf, int m, const T* R)
+    // one batch of m observations with device-resident Z / idf (slam.h:235-266 via EKF.cpp:93-129).
+    // keep_pending: leave this update's P-GEMM to a later flush() (sequential mode, deferred mode).
+    int batch_on_device(const T* dZ, const int* dIdf, int m, const T* R, bool keep_pending)
     {
         const int k  = 2 * m;
         int       rc = ensure_k(k);
@@ -583,19 +693,43 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        last_k = k;
+        if (kp + k > std::max(wcap, 0) || (kp > 0 && kp + k > std::max(defer_max, kp_call_limit)))
+        {
+            if ((rc = flush()))
+            {
+                return rc;
+            }
+        }
+        if ((rc = ensure_w(kp + k)))
+        {
+            return rc;
+        }
+        last_k   = k;
+        slot_col = kp;
         if ((rc = prof_begin(CSLAM_STAGE_GATHER)))
         {
             return rc;
         }
-        hipLaunchKernelGGL(ekf_gather_kernel<T>, dim3((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs), dim3(256), 0,
-                           stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp, lower);
+        const dim3 ggrid((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs);
+        hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp, lower);
         CSLAM_HIP_TRY(hipGetLastError());
+        if (kp > 0) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T
+        {
+            hipLaunchKernelGGL(ekf_pending_y_kernel<T>, dim3(m, (kp + 255) / 256), dim3(256), 0, stream, dX, n, dZ, dIdf, m,
+                               dW1, ldp, kp, dY);
+            CSLAM_HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(ekf_pending_corr_kernel<T>, ggrid, dim3(256), 0, stream, n, m, dW1, ldp, kp, dY, dPHT, ldp);
+            CSLAM_HIP_TRY(hipGetLastError());
+        }
         if ((rc = prof_end(CSLAM_STAGE_GATHER)) || (rc = prof_begin(CSLAM_STAGE_FACTOR)) ||
             (rc = launch_factor(dZ, dIdf, m, R)) || (rc = prof_end(CSLAM_STAGE_FACTOR)) ||
-            (rc = prof_begin(CSLAM_STAGE_GAIN)) || (rc = launch_gain(k)) || (rc = prof_end(CSLAM_STAGE_GAIN)) ||
-            (rc = prof_begin(CSLAM_STAGE_DOWNDATE)) || (rc = launch_downdate(k)) ||
-            (rc = prof_end(CSLAM_STAGE_DOWNDATE)))
+            (rc = prof_begin(CSLAM_STAGE_GAIN)) || (rc = launch_gain(k)) || (rc = prof_end(CSLAM_STAGE_GAIN)))
+        {
+            return rc;
+        }
+        kp += k;
+        const bool deferring = keep_pending || defer_max > 0;
+        if (!deferring && (rc = flush()))
         {
             return rc;
         }
@@ -605,14 +739,14 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipStreamSynchronize(stream));
             if (hFlags[1] & kFlagLltFailed)
             {
-                return eigen_fallback(k);
+                return eigen_fallback(k, deferring);
             }
         }
         return CSLAM_OK;
     }
 
     // slam.h:425-429 on the host: the device left X and P untouched (G = 0, t = 0)
-    int eigen_fallback(int k)
+    int eigen_fallback(int k, bool still_pending)
     {
         sticky_host |= CSLAM_FACTOR_FALLBACK;
         std::vector<T> S((size_t)k * k), V((size_t)k), G;
@@ -647,9 +781,23 @@ struct Ekf : EkfBase
         }
         CSLAM_HIP_TRY(hipMemcpyAsync(dU, u.data(), u.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         int rc;
-        if ((rc = launch_gain(k)) || (rc = launch_downdate(k)))
+        // the zero G made this update's W1 slot zero (a no-op wherever it was or will be applied): rewrite it
+        if ((rc = launch_gain(k)))
         {
             return rc;
+        }
+        if (!still_pending) // its P-GEMM already ran (with zeros): apply this panel alone
+        {
+            const int k8 = round_up(k, 8);
+            if (k8 > k)
+            {
+                CSLAM_HIP_TRY(hipMemset2DAsync(dW1 + (size_t)(slot_col + k) * ldp, (size_t)ldp * sizeof(T), 0,
+                                               (size_t)round_up(n, kTile) * sizeof(T), (size_t)(k8 - k), stream));
+            }
+            if ((rc = launch_downdate(dW1 + (size_t)slot_col * ldp, k)))
+            {
+                return rc;
+            }
         }
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         return CSLAM_OK;
@@ -690,15 +838,28 @@ struct Ekf : EkfBase
         }
         if (batch)
         {
-            return batch_on_device(dZ, dIdf, m, R);
+            return batch_on_device(dZ, dIdf, m, R, false);
         }
-        // EKF.cpp:457-479: m successive rank-2 updates, relinearised on the updated state each time
+        // EKF.cpp:457-479: m successive rank-2 updates, relinearised on the updated state each time.  Their m
+        // rank-2 downdates are deferred and applied by ONE P-GEMM with k = 2m at the end of the call: each
+        // observation reads the columns it needs as Ps[:,c] - Wp*Wp[c,:]^T.
+        if (seq_defer && (rc = ensure_w(kp + 2 * m)))
+        {
+            return rc;
+        }
+        kp_call_limit = seq_defer ? kp + 2 * m : 0;
         for (int i = 0; i < m; i++)
         {
-            if ((rc = batch_on_device(dZ + 2 * i, dIdf + i, 1, R)))
+            if ((rc = batch_on_device(dZ + 2 * i, dIdf + i, 1, R, seq_defer != 0)))
             {
+                kp_call_limit = 0;
                 return rc;
             }
+        }
+        kp_call_limit = 0;
+        if (defer_max == 0 && (rc = flush()))
+        {
+            return rc;
         }
         return CSLAM_OK;
     }
@@ -723,6 +884,12 @@ struct Ekf : EkfBase
         const T* R = static_cast<const T*>(Rv);
         for (int i = 0; i < q; i++)
         {
+            if (kp > 0)
+            {
+                hipLaunchKernelGGL(ekf_pending_augment_kernel<T>, dim3(1), dim3(256), 0, stream, dX, n, Z[2 * i],
+                                   Z[2 * i + 1], dW1, ldp, kp);
+                CSLAM_HIP_TRY(hipGetLastError());
+            }
             hipLaunchKernelGGL(ekf_augment_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, Z[2 * i],
                                Z[2 * i + 1], R[0], R[1], R[2], R[3], lower);
             CSLAM_HIP_TRY(hipGetLastError());
@@ -740,6 +907,10 @@ struct Ekf : EkfBase
         }
         int rc = use_device();
         if (rc)
+        {
+            return rc;
+        }
+        if ((rc = flush())) // the rank-structured Joseph update reads and rewrites all of P
         {
             return rc;
         }
@@ -791,6 +962,23 @@ struct Ekf : EkfBase
         return CSLAM_OK;
     }
 
+    int set_deferred(int max_cols) override
+    {
+        if (max_cols < 0)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "set_deferred: negative");
+        }
+        int rc = flush();
+        if (rc)
+        {
+            return rc;
+        }
+        defer_max = max_cols;
+        return max_cols > 0 ? ensure_w(max_cols) : CSLAM_OK;
+    }
+
+    int do_flush() override { return flush(); }
+
     int debug_last_update(void* PHT, void* S, void* G, void* W1, void* V, int* kout) override
     {
         int rc = use_device();
@@ -814,7 +1002,7 @@ struct Ekf : EkfBase
         }
         if (W1)
         {
-            CSLAM_HIP_TRY(hipMemcpy2DAsync(W1, (size_t)n * sizeof(T), dW1, (size_t)ldp * sizeof(T),
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(W1, (size_t)n * sizeof(T), dW1 + (size_t)slot_col * ldp, (size_t)ldp * sizeof(T),
                                            (size_t)n * sizeof(T), (size_t)k, hipMemcpyDeviceToHost, stream));
         }
         if (S)
@@ -863,7 +1051,7 @@ int Ekf<T>::ensure_tile_list(int tiles)
 }
 
 template <>
-int Ekf<float>::launch_downdate(int k)
+int Ekf<float>::launch_downdate(const float* W, int k)
 {
     const int tiles = round_up(n, kTile) / kTile;
     const dim3 grid(tiles * tiles), block(256);
@@ -871,23 +1059,23 @@ int Ekf<float>::launch_downdate(int k)
     const int  variant = tune_downdate; // 0 default; CSLAM_TUNE_DOWNDATE selects experiments
     if (variant == 14)
     {
-        hipLaunchKernelGGL((ekf_downdate2_f32<8, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+        hipLaunchKernelGGL((ekf_downdate2_f32<8, false>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
     }
     else if (variant == 1)
     {
-        hipLaunchKernelGGL((ekf_downdate2_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+        hipLaunchKernelGGL((ekf_downdate2_f32<32, false>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
     }
     else if (variant == 2)
     {
-        hipLaunchKernelGGL((ekf_downdate2_f32<32, true>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+        hipLaunchKernelGGL((ekf_downdate2_f32<32, true>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
     }
     else if (variant == 4)
     {
-        hipLaunchKernelGGL(ekf_downdate_f32, grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+        hipLaunchKernelGGL(ekf_downdate_f32, grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
     }
     else if (variant == 5)
     {
-        hipLaunchKernelGGL((ekf_downdate3_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k, tiles);
+        hipLaunchKernelGGL((ekf_downdate3_f32<32, false>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
     }
     else if (variant == 12 || variant == 13)
     {
@@ -899,34 +1087,34 @@ int Ekf<float>::launch_downdate(int k)
         const int G = std::min(n_sym_tiles, 2 * num_cus);
         if (variant == 12)
         {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8,
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
                                dTiles, n_sym_tiles);
         }
         else
         {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, false, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8,
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, false, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
                                dTiles, n_sym_tiles);
         }
     }
     else if (variant == 10)
     {
-        hipLaunchKernelGGL((ekf_downdate_sym_f32<32, true>), dim3(tiles, tiles), block, 0, stream, dP, ldp, dW1, ldp, k);
+        hipLaunchKernelGGL((ekf_downdate_sym_f32<32, true>), dim3(tiles, tiles), block, 0, stream, dP, ldp, W, ldp, k);
     }
     else if (variant == 11)
     {
-        hipLaunchKernelGGL((ekf_downdate_sym_f32<32, false>), dim3(tiles, tiles), block, 0, stream, dP, ldp, dW1, ldp, k);
+        hipLaunchKernelGGL((ekf_downdate_sym_f32<32, false>), dim3(tiles, tiles), block, 0, stream, dP, ldp, W, ldp, k);
     }
     else if (variant == 7)
     {
-        hipLaunchKernelGGL((ekf_downdate4_f32<32, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
+        hipLaunchKernelGGL((ekf_downdate4_f32<32, false>), grid, block, 0, stream, dP, ldp, W, ldp, k8, tiles);
     }
     else if (variant == 8)
     {
-        hipLaunchKernelGGL((ekf_downdate4_f32<64, true>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
+        hipLaunchKernelGGL((ekf_downdate4_f32<64, true>), grid, block, 0, stream, dP, ldp, W, ldp, k8, tiles);
     }
     else if (variant == 9)
     {
-        hipLaunchKernelGGL((ekf_downdate4_f32<64, false>), grid, block, 0, stream, dP, ldp, dW1, ldp, k8, tiles);
+        hipLaunchKernelGGL((ekf_downdate4_f32<64, false>), grid, block, 0, stream, dP, ldp, W, ldp, k8, tiles);
     }
     else
     {
@@ -939,12 +1127,12 @@ int Ekf<float>::launch_downdate(int k)
         const int G = std::min(n_sym_tiles, 2 * num_cus);
         if (lower)
         {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, false>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8,
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
                                dTiles, n_sym_tiles);
         }
         else
         {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, dW1, ldp, k8,
+            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
                                dTiles, n_sym_tiles);
         }
     }
@@ -953,29 +1141,29 @@ int Ekf<float>::launch_downdate(int k)
 }
 
 template <>
-bool Ekf<float>::launch_gain_fast(int k, int n_pad)
+bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot)
 {
-    if (k > 128 || (k > 64 && tune_factor != 0))
+    if (k > 128 || (k > 64 && tune_factor != 0 && tune_factor != 3))
     {
         return false; // du is produced by the tuned factor kernels only
     }
     hipLaunchKernelGGL(ekf_gain_mfma_f32, dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n, k, dGt, dU,
-                       dW1, dX);
+                       slot, dX);
     return true;
 }
 
 template <>
-bool Ekf<double>::launch_gain_fast(int, int)
+bool Ekf<double>::launch_gain_fast(int, int, double*)
 {
     return false;
 }
 
 template <>
-int Ekf<double>::launch_downdate(int k)
+int Ekf<double>::launch_downdate(const double* W, int k)
 {
     const int tiles_r = round_up(n, kTile) / kTile;
     const int tiles_c = round_up(n, kTile) / 64;
-    hipLaunchKernelGGL(ekf_downdate_f64, dim3(tiles_r * tiles_c), dim3(256), 0, stream, dP, ldp, dW1, ldp, k, tiles_r);
+    hipLaunchKernelGGL(ekf_downdate_f64, dim3(tiles_r * tiles_c), dim3(256), 0, stream, dP, ldp, W, ldp, k, tiles_r);
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -1062,6 +1250,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     b->ncap   = 3 + 2 * max_landmarks;
     b->ldp    = round_up(b->ncap, kTile);
     b->n      = 3;
+    if (const char* sd = getenv("CSLAM_SEQ_DEFER"))
+    {
+        b->seq_defer = atoi(sd);
+    }
     if (const char* tf = getenv("CSLAM_TUNE_FACTOR"))
     {
         b->tune_factor = atoi(tf);
@@ -1207,6 +1399,18 @@ int cslam_ekf_get_stage_times(cslam_ekf_t h, double* ms_sum, int* launches)
 {
     CSLAM_NEED(h);
     return B(h)->get_stage_times(ms_sum, launches);
+}
+
+int cslam_ekf_set_deferred(cslam_ekf_t h, int max_pending_columns)
+{
+    CSLAM_NEED(h);
+    return B(h)->set_deferred(max_pending_columns);
+}
+
+int cslam_ekf_flush(cslam_ekf_t h)
+{
+    CSLAM_NEED(h);
+    return B(h)->do_flush();
 }
 
 int cslam_ekf_debug_last_update(cslam_ekf_t h, void* PHT, void* S, void* G, void* W1, void* V, int* k)

@@ -142,6 +142,183 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
 }
 
 // ------------------------------------------------------------------------------------------------
+// Deferred downdates.  The engine may hold the covariance as  P = Ps - Wp*Wp^T  with Ps the matrix stored
+// in HBM ("stale") and Wp (n x kp) the W1 panels of updates whose P-GEMM has not been applied yet; one
+// P-GEMM with k = kp then applies them all (slam.h:260 is linear in the panels).  Every reader of P adds the
+// rank-kp correction for the few columns it touches:
+//   PHT = P*H^T = Ps*H^T - Wp*(H*Wp)^T,   Y = H*Wp (k x kp) from the 5 non-zero columns of each H row.
+// ekf_pending_y_kernel: Y[r, q] for the two rows of one observation; grid = (m, ceil(kp/256)).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_pending_y_kernel(const T* __restrict__ X, int n, const T* __restrict__ Z,
+                                                             const int* __restrict__ idf, int m,
+                                                             const T* __restrict__ Wp, int ldw, int kp,
+                                                             T* __restrict__ Y)
+{
+    __shared__ T   s_coef[10];
+    __shared__ int s_fx;
+    const int      o = blockIdx.x;
+    if (threadIdx.x == 0)
+    {
+        T v[2];
+        observe_model<T>(X, n, idf[o], Z[2 * o], Z[2 * o + 1], s_coef, v, &s_fx);
+    }
+    __syncthreads();
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= kp)
+    {
+        return;
+    }
+    const T* w  = Wp + (size_t)q * ldw;
+    const int fx = s_fx;
+    const T  w0 = w[0], w1 = w[1], w2 = w[2], wa = w[fx], wb = w[fx + 1];
+    T        y0 = s_coef[0] * w0;
+    y0 += s_coef[1] * w1;
+    y0 += s_coef[2] * w2;
+    y0 += s_coef[3] * wa;
+    y0 += s_coef[4] * wb;
+    T y1 = s_coef[5] * w0;
+    y1 += s_coef[6] * w1;
+    y1 += s_coef[7] * w2;
+    y1 += s_coef[8] * wa;
+    y1 += s_coef[9] * wb;
+    const int k = 2 * m;
+    Y[(size_t)q * k + 2 * o]     = y0;
+    Y[(size_t)q * k + 2 * o + 1] = y1;
+}
+
+// PHT -= Wp * Y^T for the 2*kGatherObs columns of one gather block; Y slice staged in LDS in chunks.
+// Same grid as ekf_gather_kernel; runs right after it on the same stream.
+constexpr int kCorrChunk = 64;
+
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_pending_corr_kernel(int n, int m, const T* __restrict__ Wp, int ldw, int kp,
+                                                                const T* __restrict__ Y, T* __restrict__ PHT,
+                                                                int ldpht)
+{
+    __shared__ T   s_y[2 * kGatherObs][kCorrChunk + 1];
+    const int      o0  = blockIdx.y * kGatherObs;
+    const int      no  = min(kGatherObs, m - o0);
+    const int      nc  = 2 * no; // PHT columns of this block
+    const int      k   = 2 * m;
+    const int      i   = blockIdx.x * 256 + threadIdx.x;
+    const bool     in  = i < n;
+    T              acc[2 * kGatherObs];
+#pragma unroll
+    for (int c = 0; c < 2 * kGatherObs; c++)
+    {
+        acc[c] = (T)0;
+    }
+    for (int q0 = 0; q0 < kp; q0 += kCorrChunk)
+    {
+        const int qn = min(kCorrChunk, kp - q0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nc * qn; e += 256)
+        {
+            const int c = e % nc, q = e / nc;
+            s_y[c][q]   = Y[(size_t)(q0 + q) * k + 2 * o0 + c];
+        }
+        __syncthreads();
+        if (in)
+        {
+            for (int q = 0; q < qn; q++)
+            {
+                const T w = Wp[(size_t)(q0 + q) * ldw + i];
+#pragma unroll
+                for (int c = 0; c < 2 * kGatherObs; c++)
+                {
+                    acc[c] += w * s_y[c][q]; // rows of s_y beyond nc are never stored
+                }
+            }
+        }
+    }
+    if (in)
+    {
+#pragma unroll
+        for (int c = 0; c < 2 * kGatherObs; c++)
+        {
+            if (c < nc)
+            {
+                T* p = PHT + (size_t)(2 * o0 + c) * ldpht + i;
+                *p   = *p - acc[c];
+            }
+        }
+    }
+}
+
+// predict under pending panels (EKF.cpp:439-443): F*(Ps - Wp Wp^T)*F^T = F Ps F^T - (F Wp)(F Wp)^T, so the
+// pose rows of every pending panel are transformed by Gv.  With the reference's n-4 stripe (quirk #2) the
+// last column's pose cross-covariance must NOT move: its stored value is adjusted by (Gv-I)*Wv*Wp[n-1,:]^T
+// so that the true value stays what the reference leaves there.  One workgroup; must run BEFORE the pose update.
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_pending_predict_kernel(const T* __restrict__ X, T* __restrict__ P, int ldp,
+                                                                   int n, T v, T swa, T dt, T* __restrict__ Wp, int ldw,
+                                                                   int kp, int fix_last)
+{
+    __shared__ T s_red[256];
+    const T      phi = X[2];
+    const T      g02 = -v * dt * dsin(swa + phi);
+    const T      g12 = v * dt * dcos(swa + phi);
+    T            part = (T)0;
+    for (int q = threadIdx.x; q < kp; q += 256)
+    {
+        T*      w  = Wp + (size_t)q * ldw;
+        const T w2 = w[2];
+        if (fix_last)
+        {
+            part += w2 * w[n - 1];
+        }
+        w[0] = w[0] + g02 * w2; // rows of Gv: [1 0 g02; 0 1 g12; 0 0 1]
+        w[1] = w[1] + g12 * w2;
+    }
+    if (fix_last) // block-uniform
+    {
+        s_red[threadIdx.x] = part;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1)
+        {
+            if ((int)threadIdx.x < st)
+            {
+                s_red[threadIdx.x] += s_red[threadIdx.x + st];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+        {
+            const T   d = s_red[0]; // Wv[2,:] . Wp[n-1,:]
+            const int c = n - 1;
+            P[(size_t)c * ldp + 0] += g02 * d;
+            P[(size_t)c * ldp + 1] += g12 * d;
+            P[(size_t)0 * ldp + c] += g02 * d;
+            P[(size_t)1 * ldp + c] += g12 * d;
+        }
+    }
+}
+
+// augment under pending panels (EKF.cpp:77-84): the new rows of the true P are Gv_a*P[0:3,:], so the new rows
+// of every pending panel are Gv_a*Wp[0:3,:].  Runs BEFORE ekf_augment_kernel appends the feature (it needs the
+// old X[2]); one workgroup.
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_pending_augment_kernel(const T* __restrict__ X, int len, T r, T b,
+                                                                   T* __restrict__ Wp, int ldw, int kp)
+{
+    const T s = dsin(X[2] + b), c = dcos(X[2] + b);
+    for (int q = threadIdx.x; q < kp; q += 256)
+    {
+        T*      w  = Wp + (size_t)q * ldw;
+        const T w0 = w[0], w1 = w[1], w2 = w[2];
+        T       a0 = (T)1 * w0;
+        a0 += (T)0 * w1;
+        a0 += (-r * s) * w2;
+        T a1 = (T)0 * w0;
+        a1 += (T)1 * w1;
+        a1 += (r * c) * w2;
+        w[len]     = a0;
+        w[len + 1] = a1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2+K3: one workgroup.  S = H*PHT + RR (slam.h:244), symmetrise (247), lower Cholesky (250 / 417-423),
 // G = inv(L) [REF_EXACT] or inv(L)^T [TEXTBOOK] (251 + quirk #1), non-finite -> zeros (252-255),
 // t = G^T V.  S and G live in LDS when they fit (lds_ld = k+1 to spread banks), else in global scratch.

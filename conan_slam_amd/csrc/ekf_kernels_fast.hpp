@@ -291,6 +291,296 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
     }
 }
 
+// Same as ekf_factor_small_kernel, but the one-wave serial section broadcasts through LDS (see inside).
+template <typename T, int K>
+__global__ void __launch_bounds__(256) ekf_factor_small2_kernel(FactorArgs<T> a, T* __restrict__ du)
+{
+    constexpr int LD = K + 1;
+    __shared__ T   S[K * LD];
+    __shared__ T   coef[(K / 2) * 10];
+    __shared__ T   V[K];
+    __shared__ T   tvec[K];
+    __shared__ int fxs[K / 2];
+    __shared__ int sflg[2];
+    __shared__ __attribute__((aligned(16))) T colb[K];
+    __shared__ __attribute__((aligned(16))) T Lr[K * (K + 4)];
+    const int      k   = 2 * a.m;
+    const int      tid = threadIdx.x;
+
+    if (tid == 0)
+    {
+        sflg[0] = 0;
+        sflg[1] = 0;
+    }
+    if (tid < K)
+    {
+        V[tid] = (T)0;
+    }
+    __syncthreads();
+    for (int o = tid; o < a.m; o += 256)
+    {
+        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    __syncthreads();
+    // S = H*PHT + RR (slam.h:244): 5-term sums in ascending column order; identity padding.
+    // Two passes with compile-time trip counts: first every global load of the thread's elements is issued
+    // (they are independent L2 hits), then the sums are formed -- one round trip instead of one per element.
+    {
+        constexpr int NE = (K * K + 255) / 256;
+        T             ph[NE][5];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e  = tid + it * 256;
+            const int r  = e & (K - 1);
+            const int c  = e / K;
+            const bool in = (e < K * K) && (r < k) && (c < k);
+            const int rc = in ? r : 0, cc = in ? c : 0; // clamped: loads stay unconditional
+            const int fx = fxs[rc >> 1];
+            const T*  p  = a.PHT + (size_t)cc * a.ldw;
+            ph[it][0]    = p[0];
+            ph[it][1]    = p[1];
+            ph[it][2]    = p[2];
+            ph[it][3]    = p[fx];
+            ph[it][4]    = p[fx + 1];
+        }
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            if (e < K * K)
+            {
+                const int r = e & (K - 1);
+                const int c = e / K;
+                T         v;
+                if (r < k && c < k)
+                {
+                    const int ob = r >> 1, ra = r & 1;
+                    const T*  cf = &coef[ob * 10 + ra * 5];
+                    T         sm = cf[0] * ph[it][0];
+                    sm += cf[1] * ph[it][1];
+                    sm += cf[2] * ph[it][2];
+                    sm += cf[3] * ph[it][3];
+                    sm += cf[4] * ph[it][4];
+                    v = sm + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0);
+                }
+                else
+                {
+                    v = (r == c) ? (T)1 : (T)0;
+                }
+                S[r + c * LD] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // makeSymmetric (slam.h:776-779)
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int r = e & (K - 1);
+        const int c = e / K;
+        if (r > c)
+        {
+            T v           = (S[r + c * LD] + S[c + r * LD]) * (T)0.5;
+            S[r + c * LD] = v;
+            S[c + r * LD] = v;
+        }
+        else if (r == c)
+        {
+            T d           = S[r + c * LD];
+            S[r + c * LD] = (d + d) * (T)0.5;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int r = e & (K - 1), c = e / K;
+        if (r < k && c < k)
+        {
+            a.dS[r + c * k] = S[r + c * LD];
+        }
+    }
+    __syncthreads();
+
+    if (tid < 64) // ---------------- one wave: lane = row of S / column of inv(L)
+    {
+        // Broadcasts go through LDS instead of v_readlane: the lane-distributed column (or the row of L) is
+        // written once and read back as 16-byte groups at a wave-uniform address, i.e. one LDS instruction
+        // per FOUR operands.  A single wave needs no barrier (its LDS operations execute in order).
+        constexpr int LDR = K + 4; // row-major copy of L for the inverse, 16-byte aligned rows
+        const int     lane = tid;
+        T             row[K];
+#pragma unroll
+        for (int c = 0; c < K; c++)
+        {
+            row[c] = (lane < K) ? S[lane + c * LD] : ((c == lane) ? (T)1 : (T)0);
+        }
+        bool failed = false;
+#pragma unroll
+        for (int j = 0; j < K; j++)
+        {
+            if (!failed)
+            {
+                const T dj = bcast(row[j], j);
+                if (dj <= (T)0)
+                {
+                    failed = true;
+                }
+                else
+                {
+                    const T sj = dsqrt(dj);
+                    row[j]     = (lane == j) ? sj : row[j] / sj;
+                    if (j + 1 < K)
+                    {
+                        if (lane < K)
+                        {
+                            colb[lane] = row[j];
+                        }
+#pragma unroll
+                        for (int c4 = ((j + 1) / 4) * 4; c4 < K; c4 += 4)
+                        {
+                            T l4[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                            {
+                                l4[e] = colb[c4 + e]; // wave-uniform addresses: merged into one wide LDS read
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                            {
+                                if (c4 + e > j)
+                                {
+                                    row[c4 + e] -= row[j] * l4[e];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+        // inv(L) by forward substitution, lane = column; rows of L come from a row-major LDS copy
+        T    x[K];
+        bool bad = false;
+        if (!failed)
+        {
+            if (lane < K)
+            {
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                {
+                    Lr[lane * LDR + c] = row[c];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < K; r++)
+            {
+                T sp[4] = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+                for (int q = 0; q < r; q++)
+                {
+                    sp[q & 3] += Lr[r * LDR + q] * x[q];
+                }
+                const T d = Lr[r * LDR + r];
+                const T sm = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+                x[r]       = (((lane == r) ? (T)1 : (T)0) - sm) / d;
+                bad        = bad || !dfinite(x[r]);
+                asm volatile("" ::: "memory"); // keep later rows' LDS reads from being hoisted (register blow-up)
+            }
+            bad = (__ballot(bad && lane < k) != 0ull);
+        }
+        const bool zero = failed || bad;
+        if (lane < K)
+        {
+#pragma unroll
+            for (int r = 0; r < K; r++)
+            {
+                const T g = zero ? (T)0 : x[r];
+                if (a.textbook)
+                {
+                    S[lane + r * LD] = g;
+                }
+                else
+                {
+                    S[r + lane * LD] = g;
+                }
+            }
+        }
+        if (lane == 0)
+        {
+            sflg[0] = failed ? 1 : 0;
+            sflg[1] = (!failed && bad) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    // outputs: G, G^T (coalesced), t = G^T V, u = G t
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int r = e & (K - 1), c = e / K;
+        if (r < k && c < k)
+        {
+            a.dG[r + c * k] = S[r + c * LD];
+        }
+    }
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int c = e & (K - 1), r = e / K;
+        if (r < k && c < k)
+        {
+            a.dGt[c + r * k] = S[r + c * LD];
+        }
+    }
+    // t = G^T V and u = G t: 4 lanes per output element, partial sums combined in a fixed order
+    {
+        const int o = tid >> 2, part = tid & 3; // 256 threads = 64 outputs x 4 parts
+        T         s = (T)0;
+        if (o < K)
+        {
+#pragma unroll 4
+            for (int r = part; r < K; r += 4)
+            {
+                s += S[r + o * LD] * V[r]; // padding rows of V are zero
+            }
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0 && o < K)
+        {
+            if (o < k)
+            {
+                a.dt[o] = s;
+            }
+            tvec[o] = (o < k) ? s : (T)0;
+        }
+        __syncthreads();
+        T s2 = (T)0;
+        if (o < K)
+        {
+#pragma unroll 4
+            for (int c = part; c < K; c += 4)
+            {
+                s2 += S[o + c * LD] * tvec[c];
+            }
+        }
+        s2 += __shfl_xor(s2, 1);
+        s2 += __shfl_xor(s2, 2);
+        if (part == 0 && o < k)
+        {
+            du[o] = s2;
+        }
+    }
+    if (tid == 0)
+    {
+        const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
+        a.flags[1]     = code;
+        if (code)
+        {
+            atomicOr(&a.flags[0], code);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2+K3, workgroup-parallel form for k <= K (K = 16, 32, 64, 128): threads = 4*K, thread = (row r, part p).
 // The matrix stays in LDS (leading dimension K+1).  Every length-j dot product of the column-by-column
@@ -606,14 +896,13 @@ __global__ void __launch_bounds__(64) ekf_gain_mfma_f32(const float* __restrict_
             xs += bb * uq[t];
         }
     }
-    const int k8 = (k + 7) & ~7; // columns [k, k8) are written as zeros for the downdate's k-blocking
 #pragma unroll
     for (int r = 0; r < 16; r++)
     {
         const int col = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (col < k8)
+        if (col < k)
         {
-            W1[(size_t)col * ldw + row0 + lj] = (col < k) ? acc[r] : 0.f;
+            W1[(size_t)col * ldw + row0 + lj] = acc[r];
         }
     }
     if (dox)

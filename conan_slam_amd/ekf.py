@@ -67,6 +67,13 @@ class EKF:
     def set_sync_mode(self, on: bool):
         check(self._L.cslam_ekf_set_sync_mode(self._h, C.c_int(1 if on else 0)))
 
+    def set_deferred(self, max_pending_columns: int):
+        """Keep up to this many W1 columns pending and apply them in one P-GEMM (0 = apply at once)."""
+        check(self._L.cslam_ekf_set_deferred(self._h, C.c_int(int(max_pending_columns))))
+
+    def flush(self):
+        check(self._L.cslam_ekf_flush(self._h))
+
     # ------------------------------------------------------------------ state
     @property
     def n(self) -> int:

@@ -114,6 +114,15 @@ int cslam_ekf_augment(cslam_ekf_t h, const void* Z, int q, const void* R);
  * josephUpdate slam.h:700-725 (evaluated in its exact rank-structured O(n^2) form). */
 int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading);
 
+/* Deferred downdates.  slam.h:260 (P = P - W1*W1^T) is linear in the W1 panels, so the engine may keep
+ * P = Ps - Wp*Wp^T with up to max_pending_columns columns of not-yet-applied panels and apply them in ONE
+ * P-GEMM (k = pending columns): every reader of P adds the rank-k correction for the columns it touches, so
+ * results are the reference's up to rounding.  0 (default) applies each update's downdate at once.  The
+ * sequential form update(batch = 0) always defers its m rank-2 downdates to one pass at the end of the call
+ * (SURVEY.md 8f rank 2).  get_state / trace / observe_heading / flush apply whatever is pending. */
+int cslam_ekf_set_deferred(cslam_ekf_t h, int max_pending_columns);
+int cslam_ekf_flush(cslam_ekf_t h);
+
 /* Per-stage device times of update() measured with HIP events on the handle's stream.
  * on = 1 starts recording (events around every stage of every update), on = 0 stops.
  * get: synchronises, writes the SUM of milliseconds per stage since profiling was switched on and the

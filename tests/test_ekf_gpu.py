@@ -327,6 +327,75 @@ def test_async_mode_skips_failed_factorisation(gpu_required):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", QUIRKS)
+@pytest.mark.parametrize("defer", [24, 64, 200])
+def test_deferred_downdates_match_the_oracle(gpu_required, dtype, quirks, defer):
+    """cslam_ekf_set_deferred: P = Ps - Wp*Wp^T with the P-GEMM applied lazily.  A mixed sequence (predict,
+    batch and sequential updates, augment, heading, state reads) must give what the immediate engine and the
+    oracle give."""
+    N, extra = 90, 3
+    eng, orc, hi = _pair(N, dtype, quirks, seed=123, extra=extra, corr=0.1)
+    eng.set_deferred(defer)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    rng = np.random.default_rng(defer)
+    nf = N
+    for step in range(7):
+        args = (83.33, 0.03 * step, Q, 73.0, 0.01)
+        m = int(rng.integers(1, 9))
+        idf = (rng.permutation(nf)[:m] + 1).astype(np.int32)
+        Z = make_obs(orc.x(), idf, dtype, seed=step)
+        batch = step != 3  # one sequential call in the middle
+        for s in (eng, orc):
+            s.predict(*args)
+            s.update(Z, R, idf, batch)
+        hi.predict(*args)
+        hi.update(Z.astype(np.float64), R.astype(np.float64), idf, batch)
+        if step == 2:
+            Zn = np.array([[300.0], [0.7]], dtype=dtype)
+            for s in (eng, orc):
+                s.augment(Zn, R)
+            hi.augment(Zn.astype(np.float64), R.astype(np.float64))
+            nf += 1
+        if step == 4:
+            for s in (eng, orc, hi):
+                s.observe_heading(0.21, True)
+        if step == 5:
+            assert abs(eng.trace() - float(np.trace(orc.p().astype(np.float64)))) <= 2e-3 * abs(eng.trace()) + 1e-6
+    X, P = eng.get_state()
+    dt = np.dtype(dtype)
+    assert_close("deferred X", X, orc.x(), 4 * X_RTOL[dt], hi.x())
+    assert_close("deferred P", P, orc.p(), 4 * P_RTOL[dt], hi.p(), fair=8.0)
+    eng.close()
+
+
+def test_deferred_and_immediate_engines_agree(gpu_required):
+    """Same inputs through the immediate and the deferred engine (f32, 1 000 landmarks, k = 32 per step)."""
+    from conan_slam_amd import EKF
+    from conan_slam_amd.synth import Workload
+
+    w = Workload(1000, 16, np.float32)
+    a = EKF(1000, dtype=np.float32, quirks=TEXTBOOK)
+    b = EKF(1000, dtype=np.float32, quirks=TEXTBOOK)
+    b.set_deferred(128)
+    for e in (a, b):
+        e.set_state(w.X0, w.P0)
+    for t in range(6):
+        v, swa = w.controls(t)
+        Z, idf = w.observations(t)
+        for e in (a, b):
+            e.predict(v, swa, w.QE, w.wb, w.dt)
+            e.update(Z, w.RE, idf, batch=True)
+    Xa, Pa = a.get_state()
+    Xb, Pb = b.get_state()
+    assert_close("X", Xb, Xa, 1e-5)
+    assert_close("P", Pb, Pa, 1e-4)
+    assert a.factor_status() == 0 and b.factor_status() == 0
+    a.close()
+    b.close()
+
+
 def test_update_device_matches_host_entry(gpu_required):
     """cslam_ekf_update_device (Z, idf already in HBM) against cslam_ekf_update (host pointers)."""
     import torch
