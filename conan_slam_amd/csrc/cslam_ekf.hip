@@ -39,7 +39,7 @@ struct EkfBase
     int         sync_mode = 1;
     int         tune_downdate = 0; // experiment selector (env CSLAM_TUNE_DOWNDATE), 0 = shipped default
     int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
-    int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (readlane one-wave for k<=64, workgroup-parallel to 128), 2 general, 3 workgroup-parallel always, 4 LDS-broadcast one-wave
+    int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (blocked 2x2 for 32<k<=64 f32, readlane one-wave otherwise up to 64, workgroup-parallel to 128), 1 readlane one-wave, 2 general, 3 workgroup-parallel always, 4 LDS-broadcast one-wave
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     hipStream_t stream   = nullptr;
 
@@ -609,6 +609,11 @@ struct Ekf : EkfBase
                 return CSLAM_OK;
             }
         }
+        if (launch_factor_blocked(a, k))
+        {
+            CSLAM_HIP_TRY(hipGetLastError());
+            return CSLAM_OK;
+        }
         if (k <= 64 && tune_factor == 4)
         {
             // one-wave factorisation with LDS broadcasts (experiment: hipcc 7.2 spills it at K = 64)
@@ -680,6 +685,8 @@ struct Ekf : EkfBase
     }
 
     int  launch_downdate(const T* W, int k);
+    bool launch_factor_blocked(const FactorArgs<T>& a, int k); // f32, 32 < k <= 64
+    bool launch_corr_fast(int k);                               // PHT -= Wp*Y^T on MFMA (f32)
     int  ensure_tile_list(int tiles);
     bool launch_gain_fast(int k, int n_pad, T* slot); // MFMA gain (f32, k <= 128 where du is available)
 
@@ -718,7 +725,11 @@ struct Ekf : EkfBase
             hipLaunchKernelGGL(ekf_pending_y_kernel<T>, dim3(m, (kp + 255) / 256), dim3(256), 0, stream, dX, n, dZ, dIdf, m,
                                dW1, ldp, kp, dY);
             CSLAM_HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(ekf_pending_corr_kernel<T>, ggrid, dim3(256), 0, stream, n, m, dW1, ldp, kp, dY, dPHT, ldp);
+            if (!launch_corr_fast(k))
+            {
+                hipLaunchKernelGGL(ekf_pending_corr_kernel<T>, ggrid, dim3(256), 0, stream, n, m, dW1, ldp, kp, dY, dPHT,
+                                   ldp);
+            }
             CSLAM_HIP_TRY(hipGetLastError());
         }
         if ((rc = prof_end(CSLAM_STAGE_GATHER)) || (rc = prof_begin(CSLAM_STAGE_FACTOR)) ||
@@ -1147,9 +1158,41 @@ bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot)
     {
         return false; // du is produced by the tuned factor kernels only
     }
-    hipLaunchKernelGGL(ekf_gain_mfma_f32, dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n, k, dGt, dU,
-                       slot, dX);
+    hipLaunchKernelGGL((ekf_panel_mfma_f32<false, true>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n,
+                       k, k, dGt, k, dU, slot, ldp, dX);
     return true;
+}
+
+template <>
+bool Ekf<float>::launch_corr_fast(int k)
+{
+    const int n_pad = round_up(n, kTile);
+    hipLaunchKernelGGL((ekf_panel_mfma_f32<true, false>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dW1, ldp, n,
+                       kp, k, dY, k, nullptr, dPHT, ldp, nullptr);
+    return true;
+}
+
+template <>
+bool Ekf<double>::launch_corr_fast(int)
+{
+    return false;
+}
+
+template <>
+bool Ekf<float>::launch_factor_blocked(const FactorArgs<float>& a, int k)
+{
+    if (k <= 32 || k > 64 || tune_factor != 0)
+    {
+        return false;
+    }
+    hipLaunchKernelGGL(ekf_factor_blocked64_f32, dim3(1), dim3(256), 0, stream, a, dU);
+    return true;
+}
+
+template <>
+bool Ekf<double>::launch_factor_blocked(const FactorArgs<double>&, int)
+{
+    return false;
 }
 
 template <>

@@ -582,6 +582,359 @@ __global__ void __launch_bounds__(256) ekf_factor_small2_kernel(FactorArgs<T> a,
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2+K3 for 32 < k <= 64 in f32, blocked 2 x 2 with 32 x 32 blocks:
+//     S = [A11 .; A21 A22]    L11 = chol(A11)            X11 = inv(L11)      (one wave, a row per lane, v_readlane)
+//                             L21 = A21 * X11^T                               (MFMA 32x32x2, operands from LDS)
+//                             L22 = chol(A22 - L21*L21^T) X22 = inv(L22)
+//                             X21 = -X22 * (L21 * X11)                        inv(L) = [X11 0; X21 X22]
+// The serial chain is two 32-column factorisations instead of one 64-column one (the readlane chain grows with
+// K^2), and the 32^3 products cost 16 MFMAs each.  Everything after the workgroup-wide S build runs in wave 0,
+// so there are no barriers inside (one wave's LDS operations are ordered).  Padding rows/cols [k,64) = identity.
+// ------------------------------------------------------------------------------------------------
+template <int KB>
+__device__ inline bool chol_rows_readlane(float (&row)[KB], int lane)
+{
+    bool failed = false;
+#pragma unroll
+    for (int j = 0; j < KB; j++)
+    {
+        if (!failed)
+        {
+            const float dj = bcast(row[j], j);
+            if (dj <= 0.f)
+            {
+                failed = true;
+            }
+            else
+            {
+                const float sj = dsqrt(dj);
+                row[j]         = (lane == j) ? sj : row[j] / sj;
+#pragma unroll
+                for (int c = j + 1; c < KB; c++)
+                {
+                    row[c] -= row[j] * bcast(row[j], c);
+                }
+            }
+        }
+    }
+    return failed;
+}
+
+template <int KB>
+__device__ inline void inv_cols_readlane(const float (&row)[KB], float (&x)[KB], int lane)
+{
+#pragma unroll
+    for (int r = 0; r < KB; r++)
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < r; q++)
+        {
+            s += bcast(row[q], r) * x[q];
+        }
+        x[r] = (((lane == r) ? 1.f : 0.f) - s) / bcast(row[r], r);
+    }
+}
+
+__global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float> a, float* __restrict__ du)
+{
+    constexpr int K = 64, LD = K + 1, KB = 32, LT = KB + 1;
+    __shared__ float S[K * LD];  // S, then L (lower blocks) in place
+    __shared__ float G[K * LD];  // inv(L), then G in its final orientation
+    __shared__ float Tt[KB * LT]; // L21 * X11
+    __shared__ float coef[(K / 2) * 10];
+    __shared__ float V[K];
+    __shared__ float tvec[K];
+    __shared__ int   fxs[K / 2];
+    __shared__ int   sflg[2];
+    const int        k   = 2 * a.m;
+    const int        tid = threadIdx.x;
+
+    if (tid == 0)
+    {
+        sflg[0] = 0;
+        sflg[1] = 0;
+    }
+    if (tid < K)
+    {
+        V[tid] = 0.f;
+    }
+    __syncthreads();
+    for (int o = tid; o < a.m; o += 256)
+    {
+        observe_model<float>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    __syncthreads();
+    {
+        constexpr int NE = (K * K) / 256;
+        float         ph[NE][5];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int  e  = tid + it * 256;
+            const int  r  = e & (K - 1);
+            const int  c  = e / K;
+            const bool in = (r < k) && (c < k);
+            const int  rc = in ? r : 0, cc = in ? c : 0;
+            const int  fx = fxs[rc >> 1];
+            const float* p = a.PHT + (size_t)cc * a.ldw;
+            ph[it][0]     = p[0];
+            ph[it][1]     = p[1];
+            ph[it][2]     = p[2];
+            ph[it][3]     = p[fx];
+            ph[it][4]     = p[fx + 1];
+        }
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1);
+            const int c = e / K;
+            float     v;
+            if (r < k && c < k)
+            {
+                const int    ob = r >> 1, ra = r & 1;
+                const float* cf = &coef[ob * 10 + ra * 5];
+                float        sm = cf[0] * ph[it][0];
+                sm += cf[1] * ph[it][1];
+                sm += cf[2] * ph[it][2];
+                sm += cf[3] * ph[it][3];
+                sm += cf[4] * ph[it][4];
+                v = sm + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : 0.f);
+            }
+            else
+            {
+                v = (r == c) ? 1.f : 0.f;
+            }
+            S[r + c * LD] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < K * K; e += 256) // makeSymmetric (slam.h:776-779)
+    {
+        const int r = e & (K - 1);
+        const int c = e / K;
+        if (r > c)
+        {
+            const float v = (S[r + c * LD] + S[c + r * LD]) * 0.5f;
+            S[r + c * LD] = v;
+            S[c + r * LD] = v;
+        }
+        else if (r == c)
+        {
+            const float d = S[r + c * LD];
+            S[r + c * LD] = (d + d) * 0.5f;
+        }
+        G[r + c * LD] = 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int r = e & (K - 1), c = e / K;
+        if (r < k && c < k)
+        {
+            a.dS[r + c * k] = S[r + c * LD];
+        }
+    }
+    __syncthreads();
+
+    if (tid < 64) // ------------------------------------------------ wave 0
+    {
+        const int lane = tid;
+        const int lj = lane & 31, lh = lane >> 5;
+        bool      failed = false;
+        float     row[KB], x[KB];
+        // ---- block (0,0): L11 and X11
+#pragma unroll
+        for (int c = 0; c < KB; c++)
+        {
+            row[c] = (lane < KB) ? S[lane + c * LD] : ((c == lane - KB) ? 1.f : 0.f);
+        }
+        failed = chol_rows_readlane<KB>(row, lane);
+        if (!failed)
+        {
+            inv_cols_readlane<KB>(row, x, lane);
+            if (lane < KB)
+            {
+#pragma unroll
+                for (int c = 0; c < KB; c++)
+                {
+                    S[lane + c * LD] = (c <= lane) ? row[c] : 0.f; // L11 (row = lane)
+                    G[c + lane * LD] = x[c];                       // X11[c][lane]: lane = column
+                }
+            }
+            // ---- L21 = A21 * X11^T : D[i][j] = sum_q X11[i][q] * A21[j][q]  (i = column of L21, j = row)
+            f32x16 acc = {0};
+#pragma unroll
+            for (int t = 0; t < KB / 2; t++)
+            {
+                const int   q  = 2 * t + lh;
+                const float av = G[lj + q * LD];        // X11[lj][q]
+                const float bv = S[(KB + lj) + q * LD]; // A21[lj][q]
+                acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                S[(KB + lj) + c * LD] = acc[r]; // L21[lj][c]
+            }
+            // ---- A22 <- A22 - L21 * L21^T
+            f32x16 acc2 = {0};
+#pragma unroll
+            for (int t = 0; t < KB / 2; t++)
+            {
+                const int   q  = 2 * t + lh;
+                const float lv = S[(KB + lj) + q * LD]; // L21[lj][q] serves as A[i=lj][q] and B[q][j=lj]
+                acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(lv, lv, acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                S[(KB + lj) + (KB + i) * LD] -= acc2[r]; // symmetric: element (j, i)
+            }
+            // ---- block (1,1): L22 and X22
+#pragma unroll
+            for (int c = 0; c < KB; c++)
+            {
+                row[c] = (lane < KB) ? S[(KB + lane) + (KB + c) * LD] : ((c == lane - KB) ? 1.f : 0.f);
+            }
+            failed = chol_rows_readlane<KB>(row, lane);
+        }
+        if (!failed)
+        {
+            inv_cols_readlane<KB>(row, x, lane);
+            if (lane < KB)
+            {
+#pragma unroll
+                for (int c = 0; c < KB; c++)
+                {
+                    S[(KB + lane) + (KB + c) * LD] = (c <= lane) ? row[c] : 0.f; // L22
+                    G[(KB + c) + (KB + lane) * LD] = x[c];                       // X22[c][lane]
+                }
+            }
+            // ---- T = L21 * X11 : D[i][j] = sum_q X11[q][i] * L21[j][q]  (i = column c of T, j = row r)
+            f32x16 acc = {0};
+#pragma unroll
+            for (int t = 0; t < KB / 2; t++)
+            {
+                const int   q  = 2 * t + lh;
+                const float av = G[q + lj * LD];        // X11[q][lj]
+                const float bv = S[(KB + lj) + q * LD]; // L21[lj][q]
+                acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Tt[lj + c * LT] = acc[r]; // T[lj][c]
+            }
+            // ---- X21 = -X22 * T : D[i][j] = sum_q T[q][i] * X22[j][q]
+            f32x16 acc3 = {0};
+#pragma unroll
+            for (int t = 0; t < KB / 2; t++)
+            {
+                const int   q  = 2 * t + lh;
+                const float av = Tt[q + lj * LT];                  // T[q][lj]
+                const float bv = G[(KB + lj) + (KB + q) * LD];     // X22[lj][q]
+                acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc3, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                G[(KB + lj) + c * LD] = -acc3[r]; // X21[lj][c]
+            }
+        }
+        if (lane == 0)
+        {
+            sflg[0] = failed ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    const bool failed = sflg[0] != 0;
+    // finite check of inv(L) (slam.h:252-255)
+    if (!failed)
+    {
+        int bad = 0;
+        for (int e = tid; e < K * K; e += 256)
+        {
+            const int r = e & (K - 1), c = e / K;
+            if (r < k && c < k)
+            {
+                bad |= !dfinite(G[r + c * LD]);
+            }
+        }
+        if (bad)
+        {
+            atomicOr(&sflg[1], 1);
+        }
+    }
+    __syncthreads();
+    const bool zero = failed || (sflg[1] != 0);
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int rr = e & (K - 1), cc = e / K;
+        if (rr < k && cc < k)
+        {
+            const float g = zero ? 0.f : (a.textbook ? G[cc + rr * LD] : G[rr + cc * LD]);
+            a.dG[rr + cc * k]  = g;
+            a.dGt[cc + rr * k] = g;
+        }
+    }
+    {
+        const int o = tid >> 2, part = tid & 3;
+        float     s1 = 0.f;
+        if (!zero)
+        {
+            for (int q = part; q < K; q += 4)
+            {
+                const float g = a.textbook ? G[o + q * LD] : G[q + o * LD]; // G[q][o]
+                s1 += g * V[q];
+            }
+        }
+        s1 += __shfl_xor(s1, 1);
+        s1 += __shfl_xor(s1, 2);
+        if (part == 0)
+        {
+            if (o < k)
+            {
+                a.dt[o] = s1;
+            }
+            tvec[o] = (o < k) ? s1 : 0.f;
+        }
+        __syncthreads();
+        float s2 = 0.f;
+        if (!zero)
+        {
+            for (int q = part; q < K; q += 4)
+            {
+                const float g = a.textbook ? G[q + o * LD] : G[o + q * LD]; // G[o][q]
+                s2 += g * tvec[q];
+            }
+        }
+        s2 += __shfl_xor(s2, 1);
+        s2 += __shfl_xor(s2, 2);
+        if (part == 0 && o < k)
+        {
+            du[o] = s2;
+        }
+    }
+    if (tid == 0)
+    {
+        const int code = (failed ? kFlagLltFailed : 0) | ((!failed && sflg[1]) ? kFlagZeroed : 0);
+        a.flags[1]     = code;
+        if (code)
+        {
+            atomicOr(&a.flags[0], code);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2+K3, workgroup-parallel form for k <= K (K = 16, 32, 64, 128): threads = 4*K, thread = (row r, part p).
 // The matrix stays in LDS (leading dimension K+1).  Every length-j dot product of the column-by-column
 // Cholesky and of the forward substitution is split over the 4 lanes of a row (q = p, p+4, ...) and combined
@@ -855,41 +1208,46 @@ __global__ void __launch_bounds__((4 * K < 64) ? 64 : 4 * K) ekf_factor_par_kern
 // PHT rows >= n are zero (never written), so W1's padding rows come out zero as the downdate needs.
 // grid = (n_pad/32, ceil(k/32)) single-wave workgroups; column tile 0 also updates X.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) ekf_gain_mfma_f32(const float* __restrict__ PHT, int ldw, int n, int k,
-                                                         const float* __restrict__ Gt, const float* __restrict__ u,
-                                                         float* __restrict__ W1, float* __restrict__ X)
+// Generic form: OUT[i, c] (= or -=) sum_q A[i, q] * Bt[q*ldb + c],  i < n_pad rows, c < nc columns, q < kq.
+//   gain:        A = PHT, kq = k,  Bt = G^T (ldb = k), OUT = W1 slot,       XUPD: X += A * u
+//   correction:  A = Wp,  kq = kp, Bt = Y   (ldb = k), OUT = PHT, SUB (PHT -= Wp * Y^T, deferred downdates)
+template <bool SUB, bool XUPD>
+__global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict__ A, int lda, int n, int kq, int nc,
+                                                          const float* __restrict__ Bt, int ldb,
+                                                          const float* __restrict__ u, float* __restrict__ OUT, int ldo,
+                                                          float* __restrict__ X)
 {
-    // one wave per workgroup, one 32x32 MFMA tile per wave: grid = (n_pad/32 row tiles, ceil(k/32) column tiles).
+    // one wave per workgroup, one 32x32 MFMA tile per wave: grid = (n_pad/32 row tiles, ceil(nc/32) column tiles).
     // Small tiles on purpose: the kernel is a latency chain (load -> MFMA -> store), so it wants many waves.
     const int  lane = threadIdx.x;
     const int  lj   = lane & 31;
     const int  lh   = lane >> 5;
     const int  row0 = blockIdx.x * 32;
     const int  c0   = blockIdx.y * 32;
-    const bool cok  = (c0 + lj) < k;
-    const int  cc   = cok ? (c0 + lj) : (k - 1); // clamped: loads are unconditional, the VALUE is selected
-    const bool dox  = (blockIdx.y == 0);
+    const bool cok  = (c0 + lj) < nc;
+    const int  cc   = cok ? (c0 + lj) : (nc - 1); // clamped: loads are unconditional, the VALUE is selected
+    const bool dox  = XUPD && (blockIdx.y == 0);
     f32x16     acc  = {0};
     float      xs   = 0.f;
-    const float* pb = PHT + row0 + lj;
+    const float* pa = A + row0 + lj;
     constexpr int NP = 32; // k-pairs per trip: every load of the trip is issued before its first MFMA
-    for (int qb = 0; qb < k; qb += 2 * NP)
+    for (int qb = 0; qb < kq; qb += 2 * NP)
     {
         float b[NP], g[NP], uq[NP];
 #pragma unroll
         for (int t = 0; t < NP; t++)
         {
             const int q  = qb + 2 * t + lh;
-            const int qc = (q < k) ? q : (k - 1);
-            b[t]         = pb[(size_t)qc * ldw];
-            g[t]         = Gt[(size_t)qc * k + cc];
-            uq[t]        = u[qc];
+            const int qc = (q < kq) ? q : (kq - 1);
+            b[t]         = pa[(size_t)qc * lda];
+            g[t]         = Bt[(size_t)qc * ldb + cc];
+            uq[t]        = XUPD ? u[qc] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < NP; t++)
         {
             const int   q  = qb + 2 * t + lh;
-            const bool  ok = q < k;
+            const bool  ok = q < kq;
             const float gg = (ok && cok) ? g[t] : 0.f;
             const float bb = ok ? b[t] : 0.f;
             acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, bb, acc, 0, 0, 0);
@@ -900,9 +1258,10 @@ __global__ void __launch_bounds__(64) ekf_gain_mfma_f32(const float* __restrict_
     for (int r = 0; r < 16; r++)
     {
         const int col = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (col < k)
+        if (col < nc)
         {
-            W1[(size_t)col * ldw + row0 + lj] = acc[r];
+            float* o = OUT + (size_t)col * ldo + row0 + lj;
+            *o       = SUB ? (*o - acc[r]) : acc[r];
         }
     }
     if (dox)
