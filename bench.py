@@ -38,6 +38,13 @@ MFMA_PEAK_TF = {"f32": 157.3, "f64": 78.6}
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", choices=["ekf", "pf"], default="ekf",
+                    help="ekf: the headline EKF update metric (default). pf: BASELINE configs[3], FastSLAM-2 observation "
+                         "steps with the particle set sharded over the ranks and the RCCL resample exchange")
+    ap.add_argument("--particles", type=int, default=512)
+    ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--pf-obs", type=int, default=8)
+    ap.add_argument("--force-resample", action="store_true", help="pf: resample on every step (worst case exchange)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--landmarks", type=int, default=5000)
@@ -90,8 +97,99 @@ def cpu_baseline(args, dtype):
     }
 
 
+def pf_main(args):
+    """BASELINE configs[3]: Np particles x Nf features, particles block-partitioned over the ranks (strong scaling:
+    the particle count is fixed).  A step = predict + sampleProposal + featureUpdate + resampleParticles
+    (PF.cpp:419-471, 502-544, 222-277, 473-500); the resample collectives run over torch.distributed (RCCL)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from conan_slam_amd.pf import ParticleShard, SingleComm, TorchComm, resample_particles
+    from conan_slam_amd.synth import Workload, normal, uniform01
+
+    dtype = np.float32
+    Np, Nf, m = args.particles, args.features, args.pf_obs
+    assert Np % world == 0, "particles must divide evenly over the ranks"
+    L = Np // world
+    w = Workload(Nf, m, dtype, seed=0, build_p=False)
+    sh = ParticleShard(L, Nf, dtype=dtype, device=local_rank, n_global=Np)
+    # every particle: map estimate = truth + N(0,1), PF = I (SURVEY 8d config 4), pose = origin with a small covariance
+    XF = np.asfortranarray(np.stack([w.X0[3::2], w.X0[4::2]]).astype(dtype))
+    PF = np.asfortranarray(np.tile(np.array([1, 0, 0, 1], dtype=dtype)[:, None], (1, Nf)))
+    Pv = np.diag([0.05, 0.05, 1e-4]).astype(dtype)
+    for i in range(L):
+        g = rank * L + i
+        pose = np.array([0.05 * normal(77, 3 * g), 0.05 * normal(77, 3 * g + 1), 0.002 * normal(77, 3 * g + 2)], dtype=dtype)
+        sh.set_particle(i, 1.0 / Np, pose, Pv, XF, PF)
+    comm = TorchComm(device=torch.device("cuda", local_rank)) if world > 1 else SingleComm()
+    total = args.warmup + args.steps
+    inputs = []
+    for t in range(total):
+        Z, idf = w.observations(t)
+        nrm = normal(500 + t, np.arange(3 * Np, dtype=np.uint64)).reshape(3, Np)[:, rank * L:(rank + 1) * L].astype(dtype)
+        inputs.append((w.controls(t), Z, idf, np.ascontiguousarray(nrm), uniform01(900 + t, np.arange(Np, dtype=np.uint64))))
+    n_resampled = 0
+
+    def step(t):
+        nonlocal n_resampled
+        (v, swa), Z, idf, nrm, u = inputs[t]
+        sh.predict(v, swa, w.QE, w.wb, w.dt)
+        sh.sample_proposal(Z, idf, w.RE, nrm)
+        sh.feature_update(Z, idf, w.RE)
+        neff, did = resample_particles(sh, comm, Np + 1 if args.force_resample else int(0.75 * Np), True, uniforms=u)
+        n_resampled += int(did)
+
+    for t in range(args.warmup):
+        step(t)
+    sh.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    n_resampled = 0
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total):
+        step(t)
+    sh.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ws = sh.get_weights()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "pf_observation_steps_per_sec", "value": args.steps / elapsed, "unit": "PF observation steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"FastSLAM-2 observation step, {Np} particles x {Nf} features, m={m} observations, "
+                                   f"particles sharded {L}/GPU over {world} GPU(s)",
+                       "particles": Np, "features": Nf, "obs_per_step": m, "resamples": n_resampled,
+                       "force_resample": bool(args.force_resample),
+                       "parallelism": f"particles/{world}; all-reduce(2) + all-gather(N) + all-to-all-v(records)",
+                       "baseline_config": "BASELINE.json configs[3]"},
+            "particle_obs_per_sec": args.steps * Np * m / elapsed,
+            "weights_finite": bool(np.all(np.isfinite(ws))),
+        }), flush=True)
+    sh.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if args.workload == "pf":
+        return pf_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -39,6 +39,7 @@ struct EkfBase
     int         sync_mode = 1;
     int         tune_downdate = 0; // experiment selector (env CSLAM_TUNE_DOWNDATE), 0 = shipped default
     int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
+    int         tune_psym     = 0; // env CSLAM_TUNE_PSYM: 0 auto, 1 single-buffer KC=64, 2 double-buffer KC=32
     int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (blocked 2x2 for 32<k<=64 f32, readlane one-wave otherwise up to 64, workgroup-parallel to 128), 1 readlane one-wave, 2 general, 3 workgroup-parallel always, 4 LDS-broadcast one-wave
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     hipStream_t stream   = nullptr;
@@ -94,6 +95,8 @@ struct Ekf : EkfBase
     bool        stage_ev_used[kStagingSlots];
     int         stage_next = 0;
     // tile list of the persistent symmetric downdate
+    long long* dStamps = nullptr; // CSLAM_FACTOR_STAMPS=1: in-kernel phase stamps of the factor kernel (diagnostic)
+    int   stamp_prints = 0;
     int2* dTiles      = nullptr;
     int   tiles_built = 0;
     int   n_sym_tiles = 0;
@@ -130,6 +133,7 @@ struct Ekf : EkfBase
         free_workspace();
         (void)hipFree(dFlags);
         (void)hipFree(dHead);
+        (void)hipFree(dStamps);
         (void)hipFree(dW1);
         (void)hipFree(dY);
         (void)hipFree(dTiles);
@@ -200,6 +204,11 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_par_kernel<T, 128>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        if (getenv("CSLAM_FACTOR_STAMPS"))
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dStamps, 16 * sizeof(long long)));
+            CSLAM_HIP_TRY(hipMemsetAsync(dStamps, 0, 16 * sizeof(long long), stream));
         }
         rc = ensure_k(64);
         if (rc)
@@ -580,6 +589,7 @@ struct Ekf : EkfBase
         a.scratchS = dScrS;
         a.scratchG = dScrG;
         a.textbook = (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1;
+        a.stamps   = dStamps;
         a.lds_S    = 1;
         a.lds_G    = 1;
         {
@@ -612,6 +622,19 @@ struct Ekf : EkfBase
         if (launch_factor_blocked(a, k))
         {
             CSLAM_HIP_TRY(hipGetLastError());
+            if (dStamps && stamp_prints < 3)
+            {
+                long long h[16];
+                CSLAM_HIP_TRY(hipMemcpyAsync(h, dStamps, sizeof(h), hipMemcpyDeviceToHost, stream));
+                CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+                fprintf(stderr, "[cslam factor stamps, cycles]");
+                for (int i = 1; i <= 8; i++)
+                {
+                    fprintf(stderr, " %d:%lld", i, h[i] - h[i - 1]);
+                }
+                fprintf(stderr, " total:%lld\n", h[8] - h[0]);
+                stamp_prints++;
+            }
             return CSLAM_OK;
         }
         if (k <= 64 && tune_factor == 4)
@@ -1136,7 +1159,13 @@ int Ekf<float>::launch_downdate(const float* W, int k)
             return rc;
         }
         const int G = std::min(n_sym_tiles, 2 * num_cus);
-        if (lower)
+        const bool dbuf = (tune_psym == 2) || (tune_psym == 0 && k8 > 64); // double-buffered panels for many columns
+        if (lower && dbuf)
+        {
+            hipLaunchKernelGGL((ekf_downdate_psym2_f32<true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8, dTiles,
+                               n_sym_tiles);
+        }
+        else if (lower)
         {
             hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
                                dTiles, n_sym_tiles);
@@ -1296,6 +1325,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* sd = getenv("CSLAM_SEQ_DEFER"))
     {
         b->seq_defer = atoi(sd);
+    }
+    if (const char* tp = getenv("CSLAM_TUNE_PSYM"))
+    {
+        b->tune_psym = atoi(tp);
     }
     if (const char* tf = getenv("CSLAM_TUNE_FACTOR"))
     {

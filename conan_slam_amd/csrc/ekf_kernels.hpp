@@ -346,6 +346,7 @@ struct FactorArgs
     int*       flags;
     T*         scratchS; // global k x (k+1) scratch used when LDS is too small
     T*         scratchG;
+    long long* stamps; // diagnostic: s_memtime at phase boundaries (nullptr in production)
     int        lds_S; // 1: S in LDS
     int        lds_G; // 1: G in LDS
     int        textbook;

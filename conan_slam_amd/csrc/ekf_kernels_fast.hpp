@@ -650,6 +650,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
     const int        k   = 2 * a.m;
     const int        tid = threadIdx.x;
 
+    if (a.stamps && tid == 0)
+    {
+        a.stamps[0] = (long long)__builtin_readcyclecounter();
+    }
     if (tid == 0)
     {
         sflg[0] = 0;
@@ -665,6 +669,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
         observe_model<float>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
         a.dV[2 * o]     = V[2 * o];
         a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    if (a.stamps && tid == 0)
+    {
+        a.stamps[1] = (long long)__builtin_readcyclecounter();
     }
     __syncthreads();
     {
@@ -711,6 +719,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
             S[r + c * LD] = v;
         }
     }
+    if (a.stamps && tid == 0)
+    {
+        a.stamps[2] = (long long)__builtin_readcyclecounter();
+    }
     __syncthreads();
     for (int e = tid; e < K * K; e += 256) // makeSymmetric (slam.h:776-779)
     {
@@ -740,6 +752,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
     }
     __syncthreads();
 
+    if (a.stamps && tid == 0)
+    {
+        a.stamps[3] = (long long)__builtin_readcyclecounter();
+    }
     if (tid < 64) // ------------------------------------------------ wave 0
     {
         const int lane = tid;
@@ -765,7 +781,11 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
                     G[c + lane * LD] = x[c];                       // X11[c][lane]: lane = column
                 }
             }
-            // ---- L21 = A21 * X11^T : D[i][j] = sum_q X11[i][q] * A21[j][q]  (i = column of L21, j = row)
+            if (a.stamps && tid == 0)
+        {
+            a.stamps[4] = (long long)__builtin_readcyclecounter();
+        }
+        // ---- L21 = A21 * X11^T : D[i][j] = sum_q X11[i][q] * A21[j][q]  (i = column of L21, j = row)
             f32x16 acc = {0};
 #pragma unroll
             for (int t = 0; t < KB / 2; t++)
@@ -796,6 +816,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 S[(KB + lj) + (KB + i) * LD] -= acc2[r]; // symmetric: element (j, i)
             }
+            if (a.stamps && tid == 0)
+            {
+                a.stamps[5] = (long long)__builtin_readcyclecounter();
+            }
             // ---- block (1,1): L22 and X22
 #pragma unroll
             for (int c = 0; c < KB; c++)
@@ -815,6 +839,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
                     S[(KB + lane) + (KB + c) * LD] = (c <= lane) ? row[c] : 0.f; // L22
                     G[(KB + c) + (KB + lane) * LD] = x[c];                       // X22[c][lane]
                 }
+            }
+            if (a.stamps && tid == 0)
+            {
+                a.stamps[6] = (long long)__builtin_readcyclecounter();
             }
             // ---- T = L21 * X11 : D[i][j] = sum_q X11[q][i] * L21[j][q]  (i = column c of T, j = row r)
             f32x16 acc = {0};
@@ -855,6 +883,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
         }
     }
     __syncthreads();
+    if (a.stamps && tid == 0)
+    {
+        a.stamps[7] = (long long)__builtin_readcyclecounter();
+    }
     const bool failed = sflg[0] != 0;
     // finite check of inv(L) (slam.h:252-255)
     if (!failed)
@@ -922,6 +954,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
         {
             du[o] = s2;
         }
+    }
+    if (a.stamps && tid == 0)
+    {
+        a.stamps[8] = (long long)__builtin_readcyclecounter();
     }
     if (tid == 0)
     {
@@ -1860,6 +1896,174 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
                     acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
                     acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
                 }
+            }
+        }
+        float* pbase = tile_base(cur);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            pv[r][0] -= acc0[r];
+            pv[r][1] -= acc1[r];
+            pv[r][2] -= acc2[r];
+            pv[r][3] -= acc3[r];
+            float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+            if (NT)
+            {
+                __builtin_nontemporal_store(pv[r], reinterpret_cast<f32x4*>(dst));
+            }
+            else
+            {
+                *reinterpret_cast<f32x4*>(dst) = pv[r];
+            }
+        }
+        if (MIRROR && cur.x != cur.y) // mirror tile (tj, ti); skipped under block-lower storage
+        {
+            float* mbase = P + (size_t)(row0 + 4 * lj) * ldp + col0 + wave * 32 + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                {
+                    const f32x4 m = {pv[4 * g + 0][b], pv[4 * g + 1][b], pv[4 * g + 2][b], pv[4 * g + 3][b]};
+                    *reinterpret_cast<f32x4*>(mbase + (size_t)b * ldp + 8 * g) = m;
+                }
+            }
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= ntiles)
+    {
+        return;
+    }
+    f32x4 pvA[16], pvB[16];
+    int2   cur = tile_list[t];
+    load_tile(tile_base(cur), pvA);
+    while (true)
+    {
+        int        tn  = t + G;
+        bool       hn  = tn < ntiles;
+        int2       nxt = hn ? tile_list[tn] : cur;
+        process(cur, pvA, hn, nxt, pvB);
+        if (!hn)
+        {
+            break;
+        }
+        t               = tn;
+        cur             = nxt;
+        tn              = t + G;
+        hn              = tn < ntiles;
+        nxt             = hn ? tile_list[tn] : cur;
+        process(cur, pvB, hn, nxt, pvA);
+        if (!hn)
+        {
+            break;
+        }
+        t   = tn;
+        cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f32), persistent symmetric form with DOUBLE-BUFFERED panels (KC = 32 x 2 buffers = 64 KiB): for k > 32
+// the LDS-DMA of the next k-chunk overlaps the MFMAs of the current one.  Used when one launch applies many
+// columns (deferred / sequential downdates), where the kernel is MFMA-bound.
+// ------------------------------------------------------------------------------------------------
+template <bool NT, bool MIRROR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+ekf_downdate_psym2_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
+                      const int2* __restrict__ tile_list, int ntiles)
+{
+    constexpr int KC = 32;
+    // two panel buffers: the DMA of k-chunk c+1 lands in one while the MFMAs of chunk c read the other
+    __shared__ __attribute__((aligned(16))) float s_pan[2][2 * KC * 128];
+
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int G    = gridDim.x;
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void*       lptr_t;
+
+    auto tile_base = [&](int2 t) -> float* {
+        return P + (size_t)(t.y * 128 + wave * 32 + 4 * lh) * ldp + t.x * 128 + 4 * lj;
+    };
+    auto load_tile = [&](float* pbase, f32x4 (&pv)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+            if (NT)
+            {
+                pv[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            }
+            else
+            {
+                pv[r] = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+    };
+    // one tile: panels -> LDS, (prefetch next P tile), MFMA, P -= acc, store in place + mirror
+    auto process = [&](int2 cur, f32x4 (&pv)[16], bool have_next, int2 nxt, f32x4 (&pn)[16]) {
+        const int row0 = cur.x * 128;
+        const int col0 = cur.y * 128;
+        f32x16    acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+        const int nch = (k8 + KC - 1) / KC;
+        auto stage = [&](int c) {
+            const int k0 = c * KC;
+            const int kc = min(KC, k8 - k0);
+            float*    sB = s_pan[c & 1];
+            float*    sA = s_pan[c & 1] + KC * 128;
+#pragma unroll
+            for (int it = 0; it < KC / 8; it++)
+            {
+                const int kkb = it * 8 + wave * 2;
+                if (kkb < kc)
+                {
+                    const float* w = W1 + (size_t)(k0 + kkb + lh) * ldw + 4 * lj;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(w + row0), (lptr_t)(sB + kkb * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(w + col0), (lptr_t)(sA + kkb * 128), 16, 0, 0);
+                }
+            }
+        };
+        __syncthreads(); // previous tile's readers of the panels are done
+        stage(0);
+        __syncthreads(); // drains the DMA (vmcnt) and publishes chunk 0
+        __builtin_amdgcn_sched_barrier(0);
+        if (have_next)
+        {
+            load_tile(tile_base(nxt), pn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < nch; c++)
+        {
+            if (c + 1 < nch)
+            {
+                stage(c + 1); // in flight while this chunk computes
+            }
+            const int    kc = min(KC, k8 - c * KC);
+            const float* sB = s_pan[c & 1];
+            const float* sA = s_pan[c & 1] + KC * 128;
+            for (int kk = 0; kk < kc; kk += 8)
+            {
+#pragma unroll
+                for (int t = 0; t < 8; t += 2)
+                {
+                    const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + t + lh) * 128 + 4 * lj]);
+                    const float  a = sA[(kk + t + lh) * 128 + wave * 32 + lj];
+                    acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+                    acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+                    acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+                    acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+                }
+            }
+            if (c + 1 < nch)
+            {
+                __syncthreads(); // chunk c+1 has landed; everyone is done with chunk c's buffer
             }
         }
         float* pbase = tile_base(cur);
