@@ -636,12 +636,102 @@ __device__ inline void inv_cols_readlane(const float (&row)[KB], float (&x)[KB],
     }
 }
 
+// LDS-broadcast forms of the two one-wave routines: the lane-distributed column (Cholesky) or the row of L
+// (inverse) is read back from LDS at a wave-uniform address, four operands per ds_read_b128, instead of one
+// v_readlane (+ SGPR wait states) per operand.  colb: KB floats; Lr: KB x (KB+4) floats, both 16-byte aligned.
+// A single wave needs no barrier (its LDS operations complete in order); the empty asm statements stop hipcc
+// from hoisting later steps' LDS reads (which blows the register budget).
+template <int KB>
+__device__ inline bool chol_rows_lds(float (&row)[KB], int lane, float* colb)
+{
+    bool failed = false;
+#pragma unroll
+    for (int j = 0; j < KB; j++)
+    {
+        if (!failed)
+        {
+            const float dj = bcast(row[j], j);
+            if (dj <= 0.f)
+            {
+                failed = true;
+            }
+            else
+            {
+                const float sj = dsqrt(dj);
+                row[j]         = (lane == j) ? sj : row[j] / sj;
+                if (j + 1 < KB)
+                {
+                    if (lane < KB)
+                    {
+                        colb[lane] = row[j];
+                    }
+#pragma unroll
+                    for (int c4 = ((j + 1) / 4) * 4; c4 < KB; c4 += 4)
+                    {
+                        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&colb[c4]);
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                        {
+                            if (c4 + e > j)
+                            {
+                                row[c4 + e] -= row[j] * l4[e];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    return failed;
+}
+
+template <int KB>
+__device__ inline void inv_cols_lds(const float (&row)[KB], float (&x)[KB], int lane, float* colb)
+{
+    // column-oriented forward substitution (lane = column of inv(L)): x starts as the identity column; step r
+    // finishes x[r] and subtracts L[q][r]*x[r] from every later x[q].  Column r of L is lane-distributed
+    // (lane q holds L[q][r] in row[r]) and is broadcast through LDS exactly like the Cholesky's rank-1 update.
+#pragma unroll
+    for (int q = 0; q < KB; q++)
+    {
+        x[q] = (lane == q) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < KB; r++)
+    {
+        x[r] = x[r] / bcast(row[r], r);
+        if (r + 1 < KB)
+        {
+            if (lane < KB)
+            {
+                colb[lane] = row[r];
+            }
+#pragma unroll
+            for (int q4 = ((r + 1) / 4) * 4; q4 < KB; q4 += 4)
+            {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&colb[q4]);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    if (q4 + e > r)
+                    {
+                        x[q4 + e] -= l4[e] * x[r];
+                    }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
 __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float> a, float* __restrict__ du)
 {
     constexpr int K = 64, LD = K + 1, KB = 32, LT = KB + 1;
     __shared__ float S[K * LD];  // S, then L (lower blocks) in place
     __shared__ float G[K * LD];  // inv(L), then G in its final orientation
     __shared__ float Tt[KB * LT]; // L21 * X11
+    __shared__ __attribute__((aligned(16))) float colb[KB];
     __shared__ float coef[(K / 2) * 10];
     __shared__ float V[K];
     __shared__ float tvec[K];
@@ -768,10 +858,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
         {
             row[c] = (lane < KB) ? S[lane + c * LD] : ((c == lane - KB) ? 1.f : 0.f);
         }
-        failed = chol_rows_readlane<KB>(row, lane);
+        failed = chol_rows_lds<KB>(row, lane, colb);
         if (!failed)
         {
-            inv_cols_readlane<KB>(row, x, lane);
+            inv_cols_lds<KB>(row, x, lane, colb);
             if (lane < KB)
             {
 #pragma unroll
@@ -826,11 +916,11 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
             {
                 row[c] = (lane < KB) ? S[(KB + lane) + (KB + c) * LD] : ((c == lane - KB) ? 1.f : 0.f);
             }
-            failed = chol_rows_readlane<KB>(row, lane);
+            failed = chol_rows_lds<KB>(row, lane, colb);
         }
         if (!failed)
         {
-            inv_cols_readlane<KB>(row, x, lane);
+            inv_cols_lds<KB>(row, x, lane, colb);
             if (lane < KB)
             {
 #pragma unroll
