@@ -37,10 +37,9 @@ struct EkfBase
     int         ldp      = 0; // padded leading dimension / column count
     int         n        = 3;
     int         sync_mode = 1;
-    int         tune_downdate = 0; // experiment selector (env CSLAM_TUNE_DOWNDATE), 0 = shipped default
+    int         tune_downdate = 0; // env CSLAM_TUNE_DOWNDATE: 0 shipped (persistent symmetric), 1 tile-per-workgroup full, 4 first version
     int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
-    int         tune_psym     = 0; // env CSLAM_TUNE_PSYM: 0 auto, 1 single-buffer KC=64, 2 double-buffer KC=32
-    int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (blocked 2x2 for 32<k<=64 f32, readlane one-wave otherwise up to 64, workgroup-parallel to 128), 1 readlane one-wave, 2 general, 3 workgroup-parallel always, 4 LDS-broadcast one-wave
+    int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (readlane one-wave up to k=64, workgroup-parallel up to 128 in f32, general beyond), 2 general always, 3 workgroup-parallel always, 5 blocked 2x2 (f32, 32<k<=64)
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     hipStream_t stream   = nullptr;
 
@@ -637,28 +636,6 @@ struct Ekf : EkfBase
             }
             return CSLAM_OK;
         }
-        if (k <= 64 && tune_factor == 4)
-        {
-            // one-wave factorisation with LDS broadcasts (experiment: hipcc 7.2 spills it at K = 64)
-            if (k <= 4)
-            {
-                hipLaunchKernelGGL((ekf_factor_small2_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
-            }
-            else if (k <= 16)
-            {
-                hipLaunchKernelGGL((ekf_factor_small2_kernel<T, 16>), dim3(1), dim3(256), 0, stream, a, dU);
-            }
-            else if (k <= 32)
-            {
-                hipLaunchKernelGGL((ekf_factor_small2_kernel<T, 32>), dim3(1), dim3(256), 0, stream, a, dU);
-            }
-            else
-            {
-                hipLaunchKernelGGL((ekf_factor_small2_kernel<T, 64>), dim3(1), dim3(256), 0, stream, a, dU);
-            }
-            CSLAM_HIP_TRY(hipGetLastError());
-            return CSLAM_OK;
-        }
         if (k <= 64 && tune_factor != 2)
         {
             // register-resident factorisation with v_readlane broadcasts (A/B: CSLAM_TUNE_FACTOR=1)
@@ -1087,85 +1064,27 @@ int Ekf<T>::ensure_tile_list(int tiles)
 template <>
 int Ekf<float>::launch_downdate(const float* W, int k)
 {
-    const int tiles = round_up(n, kTile) / kTile;
+    const int  tiles = round_up(n, kTile) / kTile;
     const dim3 grid(tiles * tiles), block(256);
-    const int  k8 = round_up(k, 8); // W1 columns [k, k8) are zero (gain kernel / memset below)
-    const int  variant = tune_downdate; // 0 default; CSLAM_TUNE_DOWNDATE selects experiments
-    if (variant == 14)
-    {
-        hipLaunchKernelGGL((ekf_downdate2_f32<8, false>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
-    }
-    else if (variant == 1)
-    {
-        hipLaunchKernelGGL((ekf_downdate2_f32<32, false>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
-    }
-    else if (variant == 2)
+    const int  k8 = round_up(k, 8); // W columns [k, k8) are zero (flush() clears the tail)
+    if (tune_downdate == 1) // A/B: one workgroup per tile, register-staged panels, full (non-symmetric) computation
     {
         hipLaunchKernelGGL((ekf_downdate2_f32<32, true>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
     }
-    else if (variant == 4)
+    else if (tune_downdate == 4) // A/B: the first version
     {
         hipLaunchKernelGGL(ekf_downdate_f32, grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
     }
-    else if (variant == 5)
-    {
-        hipLaunchKernelGGL((ekf_downdate3_f32<32, false>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
-    }
-    else if (variant == 12 || variant == 13)
-    {
-        int rc = ensure_tile_list(tiles);
-        if (rc)
-        {
-            return rc;
-        }
-        const int G = std::min(n_sym_tiles, 2 * num_cus);
-        if (variant == 12)
-        {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                               dTiles, n_sym_tiles);
-        }
-        else
-        {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, false, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                               dTiles, n_sym_tiles);
-        }
-    }
-    else if (variant == 10)
-    {
-        hipLaunchKernelGGL((ekf_downdate_sym_f32<32, true>), dim3(tiles, tiles), block, 0, stream, dP, ldp, W, ldp, k);
-    }
-    else if (variant == 11)
-    {
-        hipLaunchKernelGGL((ekf_downdate_sym_f32<32, false>), dim3(tiles, tiles), block, 0, stream, dP, ldp, W, ldp, k);
-    }
-    else if (variant == 7)
-    {
-        hipLaunchKernelGGL((ekf_downdate4_f32<32, false>), grid, block, 0, stream, dP, ldp, W, ldp, k8, tiles);
-    }
-    else if (variant == 8)
-    {
-        hipLaunchKernelGGL((ekf_downdate4_f32<64, true>), grid, block, 0, stream, dP, ldp, W, ldp, k8, tiles);
-    }
-    else if (variant == 9)
-    {
-        hipLaunchKernelGGL((ekf_downdate4_f32<64, false>), grid, block, 0, stream, dP, ldp, W, ldp, k8, tiles);
-    }
     else
     {
-        // shipped default: persistent, symmetric, non-temporal P accesses
+        // shipped: persistent, symmetric, non-temporal P accesses; mirror stores only under full storage
         int rc = ensure_tile_list(tiles);
         if (rc)
         {
             return rc;
         }
         const int G = std::min(n_sym_tiles, 2 * num_cus);
-        const bool dbuf = (tune_psym == 2) || (tune_psym == 0 && k8 > 64); // double-buffered panels for many columns
-        if (lower && dbuf)
-        {
-            hipLaunchKernelGGL((ekf_downdate_psym2_f32<true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8, dTiles,
-                               n_sym_tiles);
-        }
-        else if (lower)
+        if (lower)
         {
             hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
                                dTiles, n_sym_tiles);
@@ -1210,9 +1129,9 @@ bool Ekf<double>::launch_corr_fast(int)
 template <>
 bool Ekf<float>::launch_factor_blocked(const FactorArgs<float>& a, int k)
 {
-    if (k <= 32 || k > 64 || tune_factor != 0)
+    if (k <= 32 || k > 64 || tune_factor != 5)
     {
-        return false;
+        return false; // experiment only: measured no faster than the one-wave kernel
     }
     hipLaunchKernelGGL(ekf_factor_blocked64_f32, dim3(1), dim3(256), 0, stream, a, dU);
     return true;
@@ -1325,10 +1244,6 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* sd = getenv("CSLAM_SEQ_DEFER"))
     {
         b->seq_defer = atoi(sd);
-    }
-    if (const char* tp = getenv("CSLAM_TUNE_PSYM"))
-    {
-        b->tune_psym = atoi(tp);
     }
     if (const char* tf = getenv("CSLAM_TUNE_FACTOR"))
     {

@@ -568,15 +568,31 @@ __global__ void __launch_bounds__(256) ekf_gain_kernel(const T* __restrict__ PHT
         }
         if (c0 < k)
         {
-            for (int q = 0; q < k; q++)
+            // q in chunks of 8: the 8 row values are requested together (one memory round trip per chunk, not
+            // per q); out-of-range rows read row 0 and are zeroed by the select (no conditional loads)
+            const int ii = in ? i : 0;
+            for (int q0 = 0; q0 < k; q0 += 8)
             {
-                T        p  = in ? PHT[(size_t)q * ldw + i] : (T)0;
-                const T* gr = Gt + (size_t)q * k + c0; // G[q, c0..]
+                T pv[8];
 #pragma unroll
-                for (int cc = 0; cc < kGainCols; cc++)
+                for (int t = 0; t < 8; t++)
                 {
-                    T g = (c0 + cc < k) ? gr[cc] : (T)0;
-                    acc[cc] += p * g;
+                    const int q = (q0 + t < k) ? (q0 + t) : (k - 1);
+                    pv[t]       = PHT[(size_t)q * ldw + ii];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                {
+                    const T  p  = (in && (q0 + t < k)) ? pv[t] : (T)0;
+                    const int q = (q0 + t < k) ? (q0 + t) : (k - 1);
+                    const T* gr = Gt + (size_t)q * k + c0; // G[q, c0..]
+#pragma unroll
+                    for (int cc = 0; cc < kGainCols; cc++)
+                    {
+                        const bool ok = (c0 + cc < k);
+                        const T    g  = gr[ok ? cc : 0]; // unconditional (wave-uniform) load, value selected
+                        acc[cc] += p * (ok ? g : (T)0);
+                    }
                 }
             }
 #pragma unroll

@@ -11,6 +11,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ekf_kernels.hpp"
 
 namespace cslam
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
     // (they are independent L2 hits), then the sums are formed -- one round trip instead of one per element.
     {
         constexpr int NE = (K * K + 255) / 256;
+        const T       r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3]; // no indexed kernarg loads below
         T             ph[NE][5];
 #pragma unroll
         for (int it = 0; it < NE; it++)
@@ -106,7 +109,9 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
                     sm += cf[2] * ph[it][2];
                     sm += cf[3] * ph[it][3];
                     sm += cf[4] * ph[it][4];
-                    v = sm + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0);
+                    const int ri = ra + 2 * (c & 1);
+                    const T   rv = (ri == 0) ? r00 : ((ri == 1) ? r10 : ((ri == 2) ? r01 : r11));
+                    v = sm + (((c >> 1) == ob) ? rv : (T)0);
                 }
                 else
                 {
@@ -291,296 +296,6 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
     }
 }
 
-// Same as ekf_factor_small_kernel, but the one-wave serial section broadcasts through LDS (see inside).
-template <typename T, int K>
-__global__ void __launch_bounds__(256) ekf_factor_small2_kernel(FactorArgs<T> a, T* __restrict__ du)
-{
-    constexpr int LD = K + 1;
-    __shared__ T   S[K * LD];
-    __shared__ T   coef[(K / 2) * 10];
-    __shared__ T   V[K];
-    __shared__ T   tvec[K];
-    __shared__ int fxs[K / 2];
-    __shared__ int sflg[2];
-    __shared__ __attribute__((aligned(16))) T colb[K];
-    __shared__ __attribute__((aligned(16))) T Lr[K * (K + 4)];
-    const int      k   = 2 * a.m;
-    const int      tid = threadIdx.x;
-
-    if (tid == 0)
-    {
-        sflg[0] = 0;
-        sflg[1] = 0;
-    }
-    if (tid < K)
-    {
-        V[tid] = (T)0;
-    }
-    __syncthreads();
-    for (int o = tid; o < a.m; o += 256)
-    {
-        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
-        a.dV[2 * o]     = V[2 * o];
-        a.dV[2 * o + 1] = V[2 * o + 1];
-    }
-    __syncthreads();
-    // S = H*PHT + RR (slam.h:244): 5-term sums in ascending column order; identity padding.
-    // Two passes with compile-time trip counts: first every global load of the thread's elements is issued
-    // (they are independent L2 hits), then the sums are formed -- one round trip instead of one per element.
-    {
-        constexpr int NE = (K * K + 255) / 256;
-        T             ph[NE][5];
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            const int e  = tid + it * 256;
-            const int r  = e & (K - 1);
-            const int c  = e / K;
-            const bool in = (e < K * K) && (r < k) && (c < k);
-            const int rc = in ? r : 0, cc = in ? c : 0; // clamped: loads stay unconditional
-            const int fx = fxs[rc >> 1];
-            const T*  p  = a.PHT + (size_t)cc * a.ldw;
-            ph[it][0]    = p[0];
-            ph[it][1]    = p[1];
-            ph[it][2]    = p[2];
-            ph[it][3]    = p[fx];
-            ph[it][4]    = p[fx + 1];
-        }
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            const int e = tid + it * 256;
-            if (e < K * K)
-            {
-                const int r = e & (K - 1);
-                const int c = e / K;
-                T         v;
-                if (r < k && c < k)
-                {
-                    const int ob = r >> 1, ra = r & 1;
-                    const T*  cf = &coef[ob * 10 + ra * 5];
-                    T         sm = cf[0] * ph[it][0];
-                    sm += cf[1] * ph[it][1];
-                    sm += cf[2] * ph[it][2];
-                    sm += cf[3] * ph[it][3];
-                    sm += cf[4] * ph[it][4];
-                    v = sm + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0);
-                }
-                else
-                {
-                    v = (r == c) ? (T)1 : (T)0;
-                }
-                S[r + c * LD] = v;
-            }
-        }
-    }
-    __syncthreads();
-    // makeSymmetric (slam.h:776-779)
-    for (int e = tid; e < K * K; e += 256)
-    {
-        const int r = e & (K - 1);
-        const int c = e / K;
-        if (r > c)
-        {
-            T v           = (S[r + c * LD] + S[c + r * LD]) * (T)0.5;
-            S[r + c * LD] = v;
-            S[c + r * LD] = v;
-        }
-        else if (r == c)
-        {
-            T d           = S[r + c * LD];
-            S[r + c * LD] = (d + d) * (T)0.5;
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < K * K; e += 256)
-    {
-        const int r = e & (K - 1), c = e / K;
-        if (r < k && c < k)
-        {
-            a.dS[r + c * k] = S[r + c * LD];
-        }
-    }
-    __syncthreads();
-
-    if (tid < 64) // ---------------- one wave: lane = row of S / column of inv(L)
-    {
-        // Broadcasts go through LDS instead of v_readlane: the lane-distributed column (or the row of L) is
-        // written once and read back as 16-byte groups at a wave-uniform address, i.e. one LDS instruction
-        // per FOUR operands.  A single wave needs no barrier (its LDS operations execute in order).
-        constexpr int LDR = K + 4; // row-major copy of L for the inverse, 16-byte aligned rows
-        const int     lane = tid;
-        T             row[K];
-#pragma unroll
-        for (int c = 0; c < K; c++)
-        {
-            row[c] = (lane < K) ? S[lane + c * LD] : ((c == lane) ? (T)1 : (T)0);
-        }
-        bool failed = false;
-#pragma unroll
-        for (int j = 0; j < K; j++)
-        {
-            if (!failed)
-            {
-                const T dj = bcast(row[j], j);
-                if (dj <= (T)0)
-                {
-                    failed = true;
-                }
-                else
-                {
-                    const T sj = dsqrt(dj);
-                    row[j]     = (lane == j) ? sj : row[j] / sj;
-                    if (j + 1 < K)
-                    {
-                        if (lane < K)
-                        {
-                            colb[lane] = row[j];
-                        }
-#pragma unroll
-                        for (int c4 = ((j + 1) / 4) * 4; c4 < K; c4 += 4)
-                        {
-                            T l4[4];
-#pragma unroll
-                            for (int e = 0; e < 4; e++)
-                            {
-                                l4[e] = colb[c4 + e]; // wave-uniform addresses: merged into one wide LDS read
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; e++)
-                            {
-                                if (c4 + e > j)
-                                {
-                                    row[c4 + e] -= row[j] * l4[e];
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            asm volatile("" ::: "memory");
-        }
-        // inv(L) by forward substitution, lane = column; rows of L come from a row-major LDS copy
-        T    x[K];
-        bool bad = false;
-        if (!failed)
-        {
-            if (lane < K)
-            {
-#pragma unroll
-                for (int c = 0; c < K; c++)
-                {
-                    Lr[lane * LDR + c] = row[c];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < K; r++)
-            {
-                T sp[4] = {(T)0, (T)0, (T)0, (T)0};
-#pragma unroll
-                for (int q = 0; q < r; q++)
-                {
-                    sp[q & 3] += Lr[r * LDR + q] * x[q];
-                }
-                const T d = Lr[r * LDR + r];
-                const T sm = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-                x[r]       = (((lane == r) ? (T)1 : (T)0) - sm) / d;
-                bad        = bad || !dfinite(x[r]);
-                asm volatile("" ::: "memory"); // keep later rows' LDS reads from being hoisted (register blow-up)
-            }
-            bad = (__ballot(bad && lane < k) != 0ull);
-        }
-        const bool zero = failed || bad;
-        if (lane < K)
-        {
-#pragma unroll
-            for (int r = 0; r < K; r++)
-            {
-                const T g = zero ? (T)0 : x[r];
-                if (a.textbook)
-                {
-                    S[lane + r * LD] = g;
-                }
-                else
-                {
-                    S[r + lane * LD] = g;
-                }
-            }
-        }
-        if (lane == 0)
-        {
-            sflg[0] = failed ? 1 : 0;
-            sflg[1] = (!failed && bad) ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    // outputs: G, G^T (coalesced), t = G^T V, u = G t
-    for (int e = tid; e < K * K; e += 256)
-    {
-        const int r = e & (K - 1), c = e / K;
-        if (r < k && c < k)
-        {
-            a.dG[r + c * k] = S[r + c * LD];
-        }
-    }
-    for (int e = tid; e < K * K; e += 256)
-    {
-        const int c = e & (K - 1), r = e / K;
-        if (r < k && c < k)
-        {
-            a.dGt[c + r * k] = S[r + c * LD];
-        }
-    }
-    // t = G^T V and u = G t: 4 lanes per output element, partial sums combined in a fixed order
-    {
-        const int o = tid >> 2, part = tid & 3; // 256 threads = 64 outputs x 4 parts
-        T         s = (T)0;
-        if (o < K)
-        {
-#pragma unroll 4
-            for (int r = part; r < K; r += 4)
-            {
-                s += S[r + o * LD] * V[r]; // padding rows of V are zero
-            }
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (part == 0 && o < K)
-        {
-            if (o < k)
-            {
-                a.dt[o] = s;
-            }
-            tvec[o] = (o < k) ? s : (T)0;
-        }
-        __syncthreads();
-        T s2 = (T)0;
-        if (o < K)
-        {
-#pragma unroll 4
-            for (int c = part; c < K; c += 4)
-            {
-                s2 += S[o + c * LD] * tvec[c];
-            }
-        }
-        s2 += __shfl_xor(s2, 1);
-        s2 += __shfl_xor(s2, 2);
-        if (part == 0 && o < k)
-        {
-            du[o] = s2;
-        }
-    }
-    if (tid == 0)
-    {
-        const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
-        a.flags[1]     = code;
-        if (code)
-        {
-            atomicOr(&a.flags[0], code);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K2+K3 for 32 < k <= 64 in f32, blocked 2 x 2 with 32 x 32 blocks:
 //     S = [A11 .; A21 A22]    L11 = chol(A11)            X11 = inv(L11)      (one wave, a row per lane, v_readlane)
@@ -636,102 +351,12 @@ __device__ inline void inv_cols_readlane(const float (&row)[KB], float (&x)[KB],
     }
 }
 
-// LDS-broadcast forms of the two one-wave routines: the lane-distributed column (Cholesky) or the row of L
-// (inverse) is read back from LDS at a wave-uniform address, four operands per ds_read_b128, instead of one
-// v_readlane (+ SGPR wait states) per operand.  colb: KB floats; Lr: KB x (KB+4) floats, both 16-byte aligned.
-// A single wave needs no barrier (its LDS operations complete in order); the empty asm statements stop hipcc
-// from hoisting later steps' LDS reads (which blows the register budget).
-template <int KB>
-__device__ inline bool chol_rows_lds(float (&row)[KB], int lane, float* colb)
-{
-    bool failed = false;
-#pragma unroll
-    for (int j = 0; j < KB; j++)
-    {
-        if (!failed)
-        {
-            const float dj = bcast(row[j], j);
-            if (dj <= 0.f)
-            {
-                failed = true;
-            }
-            else
-            {
-                const float sj = dsqrt(dj);
-                row[j]         = (lane == j) ? sj : row[j] / sj;
-                if (j + 1 < KB)
-                {
-                    if (lane < KB)
-                    {
-                        colb[lane] = row[j];
-                    }
-#pragma unroll
-                    for (int c4 = ((j + 1) / 4) * 4; c4 < KB; c4 += 4)
-                    {
-                        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&colb[c4]);
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                        {
-                            if (c4 + e > j)
-                            {
-                                row[c4 + e] -= row[j] * l4[e];
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-    }
-    return failed;
-}
-
-template <int KB>
-__device__ inline void inv_cols_lds(const float (&row)[KB], float (&x)[KB], int lane, float* colb)
-{
-    // column-oriented forward substitution (lane = column of inv(L)): x starts as the identity column; step r
-    // finishes x[r] and subtracts L[q][r]*x[r] from every later x[q].  Column r of L is lane-distributed
-    // (lane q holds L[q][r] in row[r]) and is broadcast through LDS exactly like the Cholesky's rank-1 update.
-#pragma unroll
-    for (int q = 0; q < KB; q++)
-    {
-        x[q] = (lane == q) ? 1.f : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < KB; r++)
-    {
-        x[r] = x[r] / bcast(row[r], r);
-        if (r + 1 < KB)
-        {
-            if (lane < KB)
-            {
-                colb[lane] = row[r];
-            }
-#pragma unroll
-            for (int q4 = ((r + 1) / 4) * 4; q4 < KB; q4 += 4)
-            {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&colb[q4]);
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                {
-                    if (q4 + e > r)
-                    {
-                        x[q4 + e] -= l4[e] * x[r];
-                    }
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-    }
-}
-
 __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float> a, float* __restrict__ du)
 {
     constexpr int K = 64, LD = K + 1, KB = 32, LT = KB + 1;
     __shared__ float S[K * LD];  // S, then L (lower blocks) in place
     __shared__ float G[K * LD];  // inv(L), then G in its final orientation
     __shared__ float Tt[KB * LT]; // L21 * X11
-    __shared__ __attribute__((aligned(16))) float colb[KB];
     __shared__ float coef[(K / 2) * 10];
     __shared__ float V[K];
     __shared__ float tvec[K];
@@ -767,6 +392,7 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
     __syncthreads();
     {
         constexpr int NE = (K * K) / 256;
+        const float   r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3];
         float         ph[NE][5];
 #pragma unroll
         for (int it = 0; it < NE; it++)
@@ -800,7 +426,8 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
                 sm += cf[2] * ph[it][2];
                 sm += cf[3] * ph[it][3];
                 sm += cf[4] * ph[it][4];
-                v = sm + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : 0.f);
+                const float rv = ((ra + 2 * (c & 1)) == 0) ? r00 : (((ra + 2 * (c & 1)) == 1) ? r10 : (((ra + 2 * (c & 1)) == 2) ? r01 : r11));
+                v = sm + (((c >> 1) == ob) ? rv : 0.f);
             }
             else
             {
@@ -858,10 +485,10 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
         {
             row[c] = (lane < KB) ? S[lane + c * LD] : ((c == lane - KB) ? 1.f : 0.f);
         }
-        failed = chol_rows_lds<KB>(row, lane, colb);
+        failed = chol_rows_readlane<KB>(row, lane);
         if (!failed)
         {
-            inv_cols_lds<KB>(row, x, lane, colb);
+            inv_cols_readlane<KB>(row, x, lane);
             if (lane < KB)
             {
 #pragma unroll
@@ -916,11 +543,11 @@ __global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float
             {
                 row[c] = (lane < KB) ? S[(KB + lane) + (KB + c) * LD] : ((c == lane - KB) ? 1.f : 0.f);
             }
-            failed = chol_rows_lds<KB>(row, lane, colb);
+            failed = chol_rows_readlane<KB>(row, lane);
         }
         if (!failed)
         {
-            inv_cols_lds<KB>(row, x, lane, colb);
+            inv_cols_readlane<KB>(row, x, lane);
             if (lane < KB)
             {
 #pragma unroll
@@ -1105,6 +732,7 @@ __global__ void __launch_bounds__((4 * K < 64) ? 64 : 4 * K) ekf_factor_par_kern
     // S = H*PHT + RR (slam.h:244), identity padding; all loads of a thread issued before the sums
     {
         constexpr int NE = (K * K + NT - 1) / NT;
+        const T       r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3];
         T             ph[NE][5];
 #pragma unroll
         for (int it = 0; it < NE; it++)
@@ -1140,7 +768,9 @@ __global__ void __launch_bounds__((4 * K < 64) ? 64 : 4 * K) ekf_factor_par_kern
                     sm += cf[2] * ph[it][2];
                     sm += cf[3] * ph[it][3];
                     sm += cf[4] * ph[it][4];
-                    v = sm + (((c >> 1) == ob) ? a.R[ra + 2 * (c & 1)] : (T)0);
+                    const int ri = ra + 2 * (c & 1);
+                    const T   rv = (ri == 0) ? r00 : ((ri == 1) ? r10 : ((ri == 2) ? r01 : r11));
+                    v = sm + (((c >> 1) == ob) ? rv : (T)0);
                 }
                 else
                 {
@@ -1535,373 +1165,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5 (f32), version 3.  Per k-chunk: stage the two W1 panels into LDS, barrier, THEN request the P tile
-// (first chunk only) and run the MFMA loop, so the tile's HBM latency hides behind the matrix work while no
-// older load is waited on.  __builtin_amdgcn_sched_barrier pins that order (the loads have no data dependence
-// the scheduler would otherwise respect).  With KC = 64 a k <= 64 update needs one chunk and two barriers.
-// LDS = 2 * KC * 128 * 4 B (64 KiB at KC = 64 -> two workgroups per CU).
-// ------------------------------------------------------------------------------------------------
-template <int KC, bool NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_downdate3_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
-                                                             int ldw, int k, int tiles)
-{
-    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
-    float* sB = s_pan;            // rows of the tile
-    float* sA = s_pan + KC * 128; // columns of the tile
-
-    const int tid  = threadIdx.x;
-    const int wave = tid >> 6;
-    const int lane = tid & 63;
-    const int lj   = lane & 31;
-    const int lh   = lane >> 5;
-    const int tj   = blockIdx.x / tiles;
-    const int ti   = blockIdx.x % tiles;
-    const int row0 = ti * 128;
-    const int col0 = tj * 128;
-
-    constexpr int NLD = (KC * 32) / 256; // float4 per thread per panel
-    float4        pv[16];
-    float*        pbase = P + (size_t)(col0 + wave * 32 + 4 * lh) * ldp + row0 + 4 * lj;
-    f32x16        acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-
-    for (int k0 = 0; k0 < k; k0 += KC)
-    {
-        if (k0 > 0)
-        {
-            __syncthreads(); // everyone is done reading the previous chunk
-        }
-        {
-            float4 stB[NLD], stA[NLD];
-#pragma unroll
-            for (int it = 0; it < NLD; it++)
-            {
-                const int id = tid + it * 256;
-                const int kk = k0 + (id >> 5);
-                const int kc = (kk < k) ? kk : (k - 1); // unconditional load, value selected below
-                const int r4 = (id & 31) * 4;
-                const float* w = W1 + (size_t)kc * ldw;
-                stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
-                stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
-            }
-#pragma unroll
-            for (int it = 0; it < NLD; it++)
-            {
-                const int  id = tid + it * 256;
-                const bool ok = (k0 + (id >> 5)) < k;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(&sB[id * 4]) = ok ? stB[it] : z;
-                *reinterpret_cast<float4*>(&sA[id * 4]) = ok ? stA[it] : z;
-            }
-        }
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        if (k0 == 0)
-        {
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-                if (NT)
-                {
-                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-                    pv[r]         = make_float4(t[0], t[1], t[2], t[3]);
-                }
-                else
-                {
-                    pv[r] = *reinterpret_cast<const float4*>(src);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 2)
-        {
-            const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + lh) * 128 + 4 * lj]);
-            const float  a = sA[(kk + lh) * 128 + wave * 32 + lj];
-            acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
-            acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
-            acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
-            acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-    {
-        float4 v = pv[r];
-        v.x -= acc0[r];
-        v.y -= acc1[r];
-        v.z -= acc2[r];
-        v.w -= acc3[r];
-        float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-        if (NT)
-        {
-            const f32x4 t = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
-        }
-        else
-        {
-            *reinterpret_cast<float4*>(dst) = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K5 (f32), version 4: the W1 panels go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging
-// registers, no ds_write), one 1 KiB piece (two k-rows of 128 floats) per wave-instruction, LDS image
-// lane-linear.  k8 = k rounded up to 8; W1 columns [k, k8) hold zeros (written by the gain kernel), so the
-// MFMA loop runs in blocks of four k-pairs with no tail.  Per chunk: DMA panels, barrier (drains the DMA),
-// request the P tile (first chunk), MFMA blocks; epilogue P -= acc with 16-byte accesses.
-// ------------------------------------------------------------------------------------------------
-template <int KC, bool NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_downdate4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
-                                                             int ldw, int k8, int tiles)
-{
-    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
-    float* sB = s_pan;            // rows of the tile   [kk][128]
-    float* sA = s_pan + KC * 128; // columns of the tile [kk][128]
-
-    const int tid  = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int lj   = lane & 31;
-    const int lh   = lane >> 5;
-    const int tj   = blockIdx.x / tiles;
-    const int ti   = blockIdx.x % tiles;
-    const int row0 = ti * 128;
-    const int col0 = tj * 128;
-
-    float4 pv[16];
-    float* pbase = P + (size_t)(col0 + wave * 32 + 4 * lh) * ldp + row0 + 4 * lj;
-    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void*       lptr_t;
-
-    auto stage = [&](int k0, int kc) {
-#pragma unroll
-        for (int it = 0; it < KC / 8; it++)
-        {
-            const int kkb = it * 8 + wave * 2; // first of the two k-rows this wave-instruction moves
-            if (kkb < kc)
-            {
-                const float* w = W1 + (size_t)(k0 + kkb + lh) * ldw + 4 * lj;
-                __builtin_amdgcn_global_load_lds((gptr_t)(w + row0), (lptr_t)(sB + kkb * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(w + col0), (lptr_t)(sA + kkb * 128), 16, 0, 0);
-            }
-        }
-    };
-    auto mma = [&](int kc) {
-        for (int kk = 0; kk < kc; kk += 8)
-        {
-#pragma unroll
-            for (int t = 0; t < 8; t += 2)
-            {
-                const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + t + lh) * 128 + 4 * lj]);
-                const float  a = sA[(kk + t + lh) * 128 + wave * 32 + lj];
-                acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
-                acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
-                acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
-                acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
-            }
-        }
-    };
-
-    // ---- first chunk, with the P tile requested behind the barrier
-    {
-        const int kc = min(KC, k8);
-        stage(0, kc);
-        __syncthreads(); // waits for the DMA (vmcnt) and publishes the panels
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-            if (NT)
-            {
-                const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-                pv[r]         = make_float4(t[0], t[1], t[2], t[3]);
-            }
-            else
-            {
-                pv[r] = *reinterpret_cast<const float4*>(src);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mma(kc);
-    }
-    for (int k0 = KC; k0 < k8; k0 += KC)
-    {
-        const int kc = min(KC, k8 - k0);
-        __syncthreads(); // everyone is done reading the previous chunk
-        stage(k0, kc);
-        __syncthreads();
-        mma(kc);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-    {
-        float4 v = pv[r];
-        v.x -= acc0[r];
-        v.y -= acc1[r];
-        v.z -= acc2[r];
-        v.w -= acc3[r];
-        float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-        if (NT)
-        {
-            const f32x4 t = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
-        }
-        else
-        {
-            *reinterpret_cast<float4*>(dst) = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K5 (f32), symmetric form.  W1*W1^T is symmetric and so is P, so only tiles on or below the diagonal
-// (ti >= tj) are computed: half the MFMA work and half the P reads.  An off-diagonal tile's result is stored
-// twice -- in place (16-byte, row-contiguous) and transposed into the mirror tile (tj, ti): for MFMA block b
-// and register group g the four registers 4g..4g+3 of a lane are four consecutive ROWS of the mirror tile in
-// column row0+4*lj+b, i.e. one 16-byte store; a lane pair (lh = 0,1) covers 32 contiguous bytes and the four
-// groups complete a 128-byte line, which L2 merges before it leaves for HBM.
-// Contract: P is symmetric on entry (every kernel of the engine keeps it bitwise symmetric); the strictly
-// upper tiles are overwritten with the mirror of the lower result.
-// grid = tiles x tiles (x = row tile, y = column tile); workgroups above the diagonal exit at once.
-// ------------------------------------------------------------------------------------------------
-template <int KC, bool NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_downdate_sym_f32(float* __restrict__ P, int ldp,
-                                                                const float* __restrict__ W1, int ldw, int k)
-{
-    const int ti = blockIdx.x;
-    const int tj = blockIdx.y;
-    if (ti < tj)
-    {
-        return;
-    }
-    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
-    float* sB = s_pan;
-    float* sA = s_pan + KC * 128;
-
-    const int tid  = threadIdx.x;
-    const int wave = tid >> 6;
-    const int lane = tid & 63;
-    const int lj   = lane & 31;
-    const int lh   = lane >> 5;
-    const int row0 = ti * 128;
-    const int col0 = tj * 128;
-
-    constexpr int NLD = (KC * 32) / 256;
-    float4        stB[NLD], stA[NLD];
-#pragma unroll
-    for (int it = 0; it < NLD; it++)
-    {
-        const int id = tid + it * 256;
-        const int kk = id >> 5;
-        const int kc = (kk < k) ? kk : (k - 1);
-        const int r4 = (id & 31) * 4;
-        const float* w = W1 + (size_t)kc * ldw;
-        stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
-        stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
-    }
-    float4 pv[16];
-    float* pbase = P + (size_t)(col0 + wave * 32 + 4 * lh) * ldp + row0 + 4 * lj;
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-    {
-        const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-        if (NT)
-        {
-            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-            pv[r]         = make_float4(t[0], t[1], t[2], t[3]);
-        }
-        else
-        {
-            pv[r] = *reinterpret_cast<const float4*>(src);
-        }
-    }
-
-    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-    for (int k0 = 0; k0 < k; k0 += KC)
-    {
-        if (k0 > 0)
-        {
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < NLD; it++)
-            {
-                const int id = tid + it * 256;
-                const int kk = k0 + (id >> 5);
-                const int kc = (kk < k) ? kk : (k - 1);
-                const int r4 = (id & 31) * 4;
-                const float* w = W1 + (size_t)kc * ldw;
-                stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
-                stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NLD; it++)
-        {
-            const int    id = tid + it * 256;
-            const bool   ok = (k0 + (id >> 5)) < k;
-            const float4 z  = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&sB[id * 4]) = ok ? stB[it] : z;
-            *reinterpret_cast<float4*>(&sA[id * 4]) = ok ? stA[it] : z;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 2)
-        {
-            const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + lh) * 128 + 4 * lj]);
-            const float  a = sA[(kk + lh) * 128 + wave * 32 + lj];
-            acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
-            acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
-            acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
-            acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
-        }
-    }
-    // in-place store of the tile
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-    {
-        pv[r].x -= acc0[r];
-        pv[r].y -= acc1[r];
-        pv[r].z -= acc2[r];
-        pv[r].w -= acc3[r];
-        float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-        if (NT)
-        {
-            const f32x4 t = {pv[r].x, pv[r].y, pv[r].z, pv[r].w};
-            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
-        }
-        else
-        {
-            *reinterpret_cast<float4*>(dst) = pv[r];
-        }
-    }
-    // mirror tile (tj, ti): element (row0+4lj+b, col0+32w+8g+4lh+q) of this tile goes to the transposed place
-    if (ti != tj)
-    {
-        float* mbase = P + (size_t)(row0 + 4 * lj) * ldp + col0 + wave * 32 + 4 * lh;
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-        {
-            const float4 m0 = make_float4(pv[4 * g + 0].x, pv[4 * g + 1].x, pv[4 * g + 2].x, pv[4 * g + 3].x);
-            const float4 m1 = make_float4(pv[4 * g + 0].y, pv[4 * g + 1].y, pv[4 * g + 2].y, pv[4 * g + 3].y);
-            const float4 m2 = make_float4(pv[4 * g + 0].z, pv[4 * g + 1].z, pv[4 * g + 2].z, pv[4 * g + 3].z);
-            const float4 m3 = make_float4(pv[4 * g + 0].w, pv[4 * g + 1].w, pv[4 * g + 2].w, pv[4 * g + 3].w);
-            *reinterpret_cast<float4*>(mbase + (size_t)0 * ldp + 8 * g) = m0;
-            *reinterpret_cast<float4*>(mbase + (size_t)1 * ldp + 8 * g) = m1;
-            *reinterpret_cast<float4*>(mbase + (size_t)2 * ldp + 8 * g) = m2;
-            *reinterpret_cast<float4*>(mbase + (size_t)3 * ldp + 8 * g) = m3;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K5 (f32), persistent symmetric form -- the shipped P-GEMM.
 //   * symmetric: only tiles with ti >= tj are computed (half the MFMA work, half the P reads); the result of
-//     an off-diagonal tile is stored in place and transposed into the mirror tile (see ekf_downdate_sym_f32);
+//     an off-diagonal tile is stored in place and (full storage only) transposed into the mirror tile: for MFMA
+//     block b and register group g the registers 4g..4g+3 of a lane are four consecutive ROWS of the mirror
+//     tile in column row0+4*lj+b, i.e. one 16-byte store; L2 merges the pieces of a 128-byte line;
 //   * persistent: gridDim.x workgroups (two per CU) walk a host-built tile list with stride gridDim.x, and the
 //     P tile of the NEXT list entry is requested (16 x 16-byte loads per lane into a second register set)
 //     right before the MFMA loop of the current one, so every workgroup keeps 64 KiB of HBM reads in flight
@@ -1986,174 +1254,6 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
                     acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
                     acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
                 }
-            }
-        }
-        float* pbase = tile_base(cur);
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            pv[r][0] -= acc0[r];
-            pv[r][1] -= acc1[r];
-            pv[r][2] -= acc2[r];
-            pv[r][3] -= acc3[r];
-            float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-            if (NT)
-            {
-                __builtin_nontemporal_store(pv[r], reinterpret_cast<f32x4*>(dst));
-            }
-            else
-            {
-                *reinterpret_cast<f32x4*>(dst) = pv[r];
-            }
-        }
-        if (MIRROR && cur.x != cur.y) // mirror tile (tj, ti); skipped under block-lower storage
-        {
-            float* mbase = P + (size_t)(row0 + 4 * lj) * ldp + col0 + wave * 32 + 4 * lh;
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-            {
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                {
-                    const f32x4 m = {pv[4 * g + 0][b], pv[4 * g + 1][b], pv[4 * g + 2][b], pv[4 * g + 3][b]};
-                    *reinterpret_cast<f32x4*>(mbase + (size_t)b * ldp + 8 * g) = m;
-                }
-            }
-        }
-    };
-
-    int t = blockIdx.x;
-    if (t >= ntiles)
-    {
-        return;
-    }
-    f32x4 pvA[16], pvB[16];
-    int2   cur = tile_list[t];
-    load_tile(tile_base(cur), pvA);
-    while (true)
-    {
-        int        tn  = t + G;
-        bool       hn  = tn < ntiles;
-        int2       nxt = hn ? tile_list[tn] : cur;
-        process(cur, pvA, hn, nxt, pvB);
-        if (!hn)
-        {
-            break;
-        }
-        t               = tn;
-        cur             = nxt;
-        tn              = t + G;
-        hn              = tn < ntiles;
-        nxt             = hn ? tile_list[tn] : cur;
-        process(cur, pvB, hn, nxt, pvA);
-        if (!hn)
-        {
-            break;
-        }
-        t   = tn;
-        cur = nxt;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K5 (f32), persistent symmetric form with DOUBLE-BUFFERED panels (KC = 32 x 2 buffers = 64 KiB): for k > 32
-// the LDS-DMA of the next k-chunk overlaps the MFMAs of the current one.  Used when one launch applies many
-// columns (deferred / sequential downdates), where the kernel is MFMA-bound.
-// ------------------------------------------------------------------------------------------------
-template <bool NT, bool MIRROR>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-ekf_downdate_psym2_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
-                      const int2* __restrict__ tile_list, int ntiles)
-{
-    constexpr int KC = 32;
-    // two panel buffers: the DMA of k-chunk c+1 lands in one while the MFMAs of chunk c read the other
-    __shared__ __attribute__((aligned(16))) float s_pan[2][2 * KC * 128];
-
-    const int tid  = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int lj   = lane & 31;
-    const int lh   = lane >> 5;
-    const int G    = gridDim.x;
-
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void*       lptr_t;
-
-    auto tile_base = [&](int2 t) -> float* {
-        return P + (size_t)(t.y * 128 + wave * 32 + 4 * lh) * ldp + t.x * 128 + 4 * lj;
-    };
-    auto load_tile = [&](float* pbase, f32x4 (&pv)[16]) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-            if (NT)
-            {
-                pv[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-            }
-            else
-            {
-                pv[r] = *reinterpret_cast<const f32x4*>(src);
-            }
-        }
-    };
-    // one tile: panels -> LDS, (prefetch next P tile), MFMA, P -= acc, store in place + mirror
-    auto process = [&](int2 cur, f32x4 (&pv)[16], bool have_next, int2 nxt, f32x4 (&pn)[16]) {
-        const int row0 = cur.x * 128;
-        const int col0 = cur.y * 128;
-        f32x16    acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-        const int nch = (k8 + KC - 1) / KC;
-        auto stage = [&](int c) {
-            const int k0 = c * KC;
-            const int kc = min(KC, k8 - k0);
-            float*    sB = s_pan[c & 1];
-            float*    sA = s_pan[c & 1] + KC * 128;
-#pragma unroll
-            for (int it = 0; it < KC / 8; it++)
-            {
-                const int kkb = it * 8 + wave * 2;
-                if (kkb < kc)
-                {
-                    const float* w = W1 + (size_t)(k0 + kkb + lh) * ldw + 4 * lj;
-                    __builtin_amdgcn_global_load_lds((gptr_t)(w + row0), (lptr_t)(sB + kkb * 128), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(w + col0), (lptr_t)(sA + kkb * 128), 16, 0, 0);
-                }
-            }
-        };
-        __syncthreads(); // previous tile's readers of the panels are done
-        stage(0);
-        __syncthreads(); // drains the DMA (vmcnt) and publishes chunk 0
-        __builtin_amdgcn_sched_barrier(0);
-        if (have_next)
-        {
-            load_tile(tile_base(nxt), pn);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        for (int c = 0; c < nch; c++)
-        {
-            if (c + 1 < nch)
-            {
-                stage(c + 1); // in flight while this chunk computes
-            }
-            const int    kc = min(KC, k8 - c * KC);
-            const float* sB = s_pan[c & 1];
-            const float* sA = s_pan[c & 1] + KC * 128;
-            for (int kk = 0; kk < kc; kk += 8)
-            {
-#pragma unroll
-                for (int t = 0; t < 8; t += 2)
-                {
-                    const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + t + lh) * 128 + 4 * lj]);
-                    const float  a = sA[(kk + t + lh) * 128 + wave * 32 + lj];
-                    acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
-                    acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
-                    acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
-                    acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
-                }
-            }
-            if (c + 1 < nch)
-            {
-                __syncthreads(); // chunk c+1 has landed; everyone is done with chunk c's buffer
             }
         }
         float* pbase = tile_base(cur);
