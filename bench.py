@@ -295,6 +295,17 @@ def main():
     dd_bytes = 2.0 * n * n * esize + 1.0 * n * k_launch * esize
     dd_flops = 2.0 * n * n * k_launch
     achieved = dd_bytes / dd_s / 1e9 if dd_s > 0 else None
+    storage = "full" if (os.environ.get("CSLAM_STORAGE") == "full" or args.dtype == "f64" or
+                         os.environ.get("CSLAM_TUNE_DOWNDATE", "0") != "0") else "lower"
+    kernel_name = ("ekf_downdate_psym_f32<64,true,%s>" % ("false" if storage == "lower" else "true")
+                   if args.dtype == "f32" and os.environ.get("CSLAM_TUNE_DOWNDATE", "0") == "0" else "ekf_downdate_" + args.dtype)
+    traffic = None  # physical HBM bytes per launch: from the committed rocprofv3 --pmc summary of this exact configuration
+    try:
+        for e in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]:
+            if (e["kernel"], e["landmarks"], e["k"], e["dtype"]) == (kernel_name, args.landmarks, int(k_launch), args.dtype):
+                traffic = e["traffic_bytes"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "ekf_update_steps_per_sec",
         "value": world * args.steps / elapsed,
@@ -321,13 +332,17 @@ def main():
             "baseline_config": "BASELINE.json configs[2]" if (args.landmarks, args.dtype) == (5000, "f32") else "custom",
         },
         "roofline": {
-            "kernel": "ekf_downdate_" + args.dtype,
+            "kernel": kernel_name,
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
+            "note": "achieved uses SURVEY 8d's full-storage algorithmic bytes (2 n^2 s + n k s); the symmetric kernel "
+                    "physically moves about half of them (traffic), so frac can exceed 1; issued MFMA flops are n^2 k "
+                    "(half of the 2 n^2 k the mfma_* fields are normalised by)",
             "algorithmic_bytes_per_launch": dd_bytes,
             "launch_us": dd_s * 1e6,
             "launches_timed": dd_cnt,

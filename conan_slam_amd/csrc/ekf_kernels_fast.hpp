@@ -34,6 +34,11 @@ __device__ inline double bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// reciprocal square root of the pivot: one v_rsq_f32 (<= 1 ulp) for f32 instead of the ~35-instruction
+// IEEE sqrt + divide chain that otherwise sits on the serial path of every column; exact for f64.
+__device__ inline float  pivot_rsqrt(float d) { return __builtin_amdgcn_rsqf(d); }
+__device__ inline double pivot_rsqrt(double d) { return 1.0 / sqrt(d); }
+
 // ------------------------------------------------------------------------------------------------
 // K2+K3 for k <= K (K a power of two <= 64).  Same outputs as ekf_factor_kernel plus du = G*(G^T V).
 // Padding rows/columns [k, K) of S are the identity, so L and inv(L) are blkdiag(., I).
@@ -160,6 +165,7 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
             row[c] = (lane < K) ? S[lane + c * LD] : ((c == lane) ? (T)1 : (T)0);
         }
         bool failed = false;
+        T    rdiag[K]; // wave-uniform reciprocals of the diagonal of L
         // right-looking lower Cholesky; a pivot <= 0 is the LLT failure of slam.h:421
 #pragma unroll
         for (int j = 0; j < K; j++)
@@ -173,8 +179,9 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
                 }
                 else
                 {
-                    const T sj = dsqrt(dj);
-                    row[j]     = (lane == j) ? sj : row[j] / sj;
+                    const T rs = pivot_rsqrt(dj); // 1/sqrt(pivot)
+                    row[j]     = (lane == j) ? dj * rs : row[j] * rs;
+                    rdiag[j]   = rs; // 1/L[j][j], reused by the inverse
 #pragma unroll
                     for (int c = j + 1; c < K; c++)
                     {
@@ -198,8 +205,7 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
                 {
                     s += bcast(row[q], r) * x[q];
                 }
-                const T d = bcast(row[r], r);
-                x[r]      = (((lane == r) ? (T)1 : (T)0) - s) / d;
+                x[r] = (((lane == r) ? (T)1 : (T)0) - s) * rdiag[r];
                 bad       = bad || !dfinite(x[r]);
             }
             bad = (__ballot(bad && lane < k) != 0ull);
