@@ -37,7 +37,7 @@ struct EkfBase
     int         ldp      = 0; // padded leading dimension / column count
     int         n        = 3;
     int         sync_mode = 1;
-    int         tune_downdate = 0; // env CSLAM_TUNE_DOWNDATE: 0 shipped (persistent symmetric), 1 tile-per-workgroup full, 4 first version
+    int         tune_downdate = 0; // env CSLAM_TUNE_DOWNDATE: 0 shipped (persistent symmetric, pipelined for k<=64), 1 tile-per-workgroup full, 2 persistent symmetric unpipelined, 4 first version
     int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
     int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (readlane one-wave up to k=64, workgroup-parallel up to 128 in f32, general beyond), 2 general always, 3 workgroup-parallel always, 5 blocked 2x2 (f32, 32<k<=64)
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
@@ -96,6 +96,14 @@ struct Ekf : EkfBase
     // tile list of the persistent symmetric downdate
     long long* dStamps = nullptr; // CSLAM_FACTOR_STAMPS=1: in-kernel phase stamps of the factor kernel (diagnostic)
     int   stamp_prints = 0;
+    long long* dPsymStamps = nullptr; // CSLAM_PSYM_STAMPS=1
+    int*       dTicket     = nullptr; // two tile-ticket counters used alternately by successive P-GEMM launches
+    unsigned   launch_parity = 0;
+    int        psym_nt = -1; // CSLAM_PSYM_NT: non-temporal P accesses in the P-GEMM (-1: by footprint)
+    unsigned long long* dHwIds = nullptr; // CSLAM_PSYM_HWID=1 (diagnostics)
+    int        hwid_prints = 0;
+    int        stagger_mode = 0, stagger_cycles = 0; // CSLAM_PSYM_STAGGER=mode,cycles
+    int   stamp_prints2 = 0;
     int2* dTiles      = nullptr;
     int   tiles_built = 0;
     int   n_sym_tiles = 0;
@@ -133,6 +141,9 @@ struct Ekf : EkfBase
         (void)hipFree(dFlags);
         (void)hipFree(dHead);
         (void)hipFree(dStamps);
+        (void)hipFree(dPsymStamps);
+        (void)hipFree(dHwIds);
+        (void)hipFree(dTicket);
         (void)hipFree(dW1);
         (void)hipFree(dY);
         (void)hipFree(dTiles);
@@ -203,6 +214,29 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_par_kernel<T, 128>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        if (getenv("CSLAM_PSYM_STAMPS"))
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dPsymStamps, 64 * sizeof(long long)));
+            CSLAM_HIP_TRY(hipMemsetAsync(dPsymStamps, 0, 64 * sizeof(long long), stream));
+        }
+        CSLAM_HIP_TRY(hipMalloc(&dTicket, 2 * sizeof(int)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dTicket, 0, 2 * sizeof(int), stream));
+        if (const char* sv = getenv("CSLAM_PSYM_NT"))
+        {
+            psym_nt = atoi(sv);
+        }
+        if (getenv("CSLAM_PSYM_HWID"))
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dHwIds, 4 * 1024 * sizeof(unsigned long long)));
+            CSLAM_HIP_TRY(hipMemsetAsync(dHwIds, 0, 4 * 1024 * sizeof(unsigned long long), stream));
+        }
+        if (const char* sv = getenv("CSLAM_PSYM_STAGGER"))
+        {
+            if (sscanf(sv, "%d,%d", &stagger_mode, &stagger_cycles) != 2)
+            {
+                stagger_mode = stagger_cycles = 0;
+            }
         }
         if (getenv("CSLAM_FACTOR_STAMPS"))
         {
@@ -1084,15 +1118,85 @@ int Ekf<float>::launch_downdate(const float* W, int k)
             return rc;
         }
         const int G = std::min(n_sym_tiles, 2 * num_cus);
-        if (lower)
+        if (k8 <= 64 && tune_downdate != 2)
+        {
+            launch_parity++;
+            // software-pipelined across tiles (one panel chunk per tile)
+            // block-lower P that fits the 256 MB infinity cache is better served by ordinary (cached) accesses:
+            // measured 94 vs 101 us at n = 10003 (207 MB); above that, streaming hints win
+            const bool nt = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
+            if (lower && !nt)
+            {
+                hipLaunchKernelGGL((ekf_downdate_psym3_f32<false, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
+                                   tiles_built, n_sym_tiles, dTicket + (launch_parity & 1),
+                                   dTicket + ((launch_parity + 1) & 1), stagger_mode, stagger_cycles, dHwIds);
+            }
+            else if (lower)
+            {
+                hipLaunchKernelGGL((ekf_downdate_psym3_f32<true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
+                                   tiles_built, n_sym_tiles, dTicket + (launch_parity & 1),
+                                   dTicket + ((launch_parity + 1) & 1), stagger_mode, stagger_cycles, dHwIds);
+            }
+            else
+            {
+                hipLaunchKernelGGL((ekf_downdate_psym3_f32<true, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
+                                   tiles_built, n_sym_tiles, dTicket + (launch_parity & 1),
+                                   dTicket + ((launch_parity + 1) & 1), stagger_mode, stagger_cycles, dHwIds);
+            }
+            if (dHwIds && hwid_prints < 3)
+            {
+                hwid_prints++;
+                std::vector<unsigned long long> h(4 * G);
+                CSLAM_HIP_TRY(hipMemcpyAsync(h.data(), dHwIds, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost, stream));
+                CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+                // per-workgroup start / end (s_memtime) relative to the earliest start, grouped by tile count
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (int i = 0; i < G; i++)
+                {
+                    t0 = std::min(t0, h[4 * i + 2]);
+                    t1 = std::max(t1, h[4 * i + 3]);
+                }
+                double s_start = 0, s_end = 0, mx_start = 0, mn_end = 1e30;
+                for (int i = 0; i < G; i++)
+                {
+                    const double st = (double)(h[4 * i + 2] - t0), en = (double)(h[4 * i + 3] - t0);
+                    s_start += st;
+                    s_end += en;
+                    mx_start = std::max(mx_start, st);
+                    mn_end   = std::min(mn_end, en);
+                }
+                fprintf(stderr, "[cslam] psym3 timeline (10 ns ticks): span %llu | start avg %.0f max %.0f | end min %.0f avg %.0f\n",
+                        t1 - t0, s_start / G, mx_start, mn_end, s_end / G);
+                fprintf(stderr, "[cslam] sample (wg: xcc start end):");
+                for (int i = 0; i < G; i += 32)
+                {
+                    fprintf(stderr, " %d:%llu %llu %llu", i, h[4 * i + 1] & 15, h[4 * i + 2] - t0, h[4 * i + 3] - t0);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+        else if (lower)
         {
             hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                               dTiles, n_sym_tiles);
+                               dTiles, n_sym_tiles, dPsymStamps);
         }
         else
         {
             hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                               dTiles, n_sym_tiles);
+                               dTiles, n_sym_tiles, dPsymStamps);
+        }
+        if (dPsymStamps && stamp_prints2 < 2)
+        {
+            long long h[64];
+            CSLAM_HIP_TRY(hipMemcpyAsync(h, dPsymStamps, sizeof(h), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            fprintf(stderr, "[cslam psym stamps, cycles per phase: wait-top | dma | mfma | epilogue+next]\n");
+            for (int t = 0; t + 4 < 28; t += 4)
+            {
+                fprintf(stderr, "  tile %d: %lld | %lld | %lld | %lld\n", t / 4, h[t + 1] - h[t], h[t + 2] - h[t + 1],
+                        h[t + 3] - h[t + 2], h[t + 4] - h[t + 3]);
+            }
+            stamp_prints2++;
         }
     }
     CSLAM_HIP_TRY(hipGetLastError());
@@ -1255,14 +1359,14 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     }
     // Block-lower storage: only 128x128 tiles on/below the tile diagonal of the symmetric P are maintained
     // (the P-GEMM then writes each tile once).  Needs the persistent symmetric kernel -> f32 default path only.
-    b->lower = (dtype == CSLAM_F32 && b->tune_downdate == 0) ? 1 : 0;
+    b->lower = (dtype == CSLAM_F32 && (b->tune_downdate == 0 || b->tune_downdate == 2)) ? 1 : 0;
     if (const char* sv = getenv("CSLAM_STORAGE"))
     {
         if (!strcmp(sv, "full"))
         {
             b->lower = 0;
         }
-        else if (!strcmp(sv, "lower") && dtype == CSLAM_F32 && b->tune_downdate == 0)
+        else if (!strcmp(sv, "lower") && dtype == CSLAM_F32 && (b->tune_downdate == 0 || b->tune_downdate == 2))
         {
             b->lower = 1;
         }

@@ -1187,8 +1187,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int KC, bool NT, bool MIRROR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
-                      const int2* __restrict__ tile_list, int ntiles)
+                      const int2* __restrict__ tile_list, int ntiles, long long* __restrict__ stamps)
 {
+    int        stamp_slot = 0; // diagnostic: s_memtime of workgroup 0 at the phase boundaries of its first tiles
+    const bool stamping   = (stamps != nullptr) && blockIdx.x == 0 && threadIdx.x == 0;
+    auto       stamp      = [&]() {
+        if (stamping && stamp_slot < 60)
+        {
+            stamps[stamp_slot++] = (long long)__builtin_readcyclecounter();
+        }
+    };
+
     __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
     float* sB = s_pan;            // rows of the tile   [kk][128]
     float* sA = s_pan + KC * 128; // columns of the tile [kk][128]
@@ -1229,7 +1238,9 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
         for (int k0 = 0; k0 < k8; k0 += KC)
         {
             const int kc = min(KC, k8 - k0);
+            stamp();
             __syncthreads(); // previous readers of the panels are done
+            stamp();
 #pragma unroll
             for (int it = 0; it < KC / 8; it++)
             {
@@ -1242,6 +1253,7 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
                 }
             }
             __syncthreads(); // drains the DMA (vmcnt) and publishes the panels
+            stamp();
             __builtin_amdgcn_sched_barrier(0);
             if (k0 == 0 && have_next)
             {
@@ -1262,6 +1274,7 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
                 }
             }
         }
+        stamp();
         float* pbase = tile_base(cur);
 #pragma unroll
         for (int r = 0; r < 16; r++)
@@ -1326,6 +1339,259 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
         }
         t   = tn;
         cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (f32), persistent symmetric form, software-pipelined across tiles (k8 <= 64: one panel chunk per tile).
+// Same tiling, MFMA mapping and register plan as ekf_downdate_psym_f32; what changes is the ORDER of the
+// memory operations, so that nothing ever waits for a store:
+//     loop over this workgroup's tiles:
+//        s_waitcnt vmcnt(#stores of the previous tile)   -> the panel DMA of THIS tile (issued before those
+//        s_barrier                                           stores) has landed; the stores keep draining
+//        request the NEXT tile's P values (16 loads/lane, second register set)
+//        MFMA loop over the panels in LDS
+//        s_barrier                                        -> every wave is done reading the panels
+//        LDS-DMA of the NEXT tile's panels                -> lands while the epilogue runs
+//        epilogue: P -= acc, 16 stores (+16 mirror stores under full storage)
+// vmcnt retires in order, so "all but the N youngest" with N = the stores issued after the DMA is exactly
+// "the DMA is complete".  __syncthreads() is not used in the loop: its fence would wait for vmcnt(0).
+// ------------------------------------------------------------------------------------------------
+template <bool NT, bool MIRROR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8, int tiles,
+                       int ntiles, int* __restrict__ ticket, int* __restrict__ ticket_reset, int stagger_mode,
+                       int stagger_cycles, unsigned long long* __restrict__ hwids)
+{
+    constexpr int KC = 64;
+    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
+    __shared__ int s_next[2];
+    float* sB = s_pan;            // rows of the tile   [kk][128]
+    float* sA = s_pan + KC * 128; // columns of the tile [kk][128]
+
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int G    = gridDim.x;
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void*       lptr_t;
+
+    // ticket t -> tile (x = tile row, y = tile column), x >= y, column after column:
+    // column c starts at f(c) = c*tiles - c(c-1)/2
+    auto tile_of = [&](int t) -> int2 {
+        const float b = 2.0f * tiles + 1.0f;
+        int         c = (int)((b - sqrtf(fmaxf(b * b - 8.0f * (float)t, 0.0f))) * 0.5f);
+        c             = min(max(c, 0), tiles - 1);
+        auto f        = [&](int cc) { return cc * tiles - ((cc * (cc - 1)) >> 1); };
+        while (c + 1 < tiles && f(c + 1) <= t)
+        {
+            c++;
+        }
+        while (c > 0 && f(c) > t)
+        {
+            c--;
+        }
+        return make_int2(c + (t - f(c)), c);
+    };
+    auto tile_base = [&](int2 t) -> float* {
+        return P + (size_t)(t.y * 128 + wave * 32 + 4 * lh) * ldp + t.x * 128 + 4 * lj;
+    };
+    auto load_tile = [&](float* pbase, f32x4 (&pv)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+            if (NT)
+            {
+                pv[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            }
+            else
+            {
+                pv[r] = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+    };
+    auto dma_panels = [&](int2 t) {
+        const int row0 = t.x * 128, col0 = t.y * 128;
+#pragma unroll
+        for (int it = 0; it < KC / 8; it++)
+        {
+            const int kkb = it * 8 + wave * 2;
+            if (kkb < k8)
+            {
+                const float* w = W1 + (size_t)(kkb + lh) * ldw + 4 * lj;
+                __builtin_amdgcn_global_load_lds((gptr_t)(w + row0), (lptr_t)(sB + kkb * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(w + col0), (lptr_t)(sA + kkb * 128), 16, 0, 0);
+            }
+        }
+    };
+    // FIRST: the first tile of this workgroup (its DMA is the youngest memory operation: wait for all);
+    // otherwise at least 16 stores were issued after the DMA that fed this tile (32 for a mirrored tile:
+    // waiting down to 16 then also retires the older half of those, which is harmless).
+    // The waits are the s_waitcnt builtin, not inline asm, so that the compiler's own wait-count pass sees
+    // them and does not add a vmcnt(0) in front of the first LDS read.
+    // gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
+    // Tiles are handed out dynamically: the first two of a workgroup are blockIdx.x and blockIdx.x + G, every
+    // later one comes from an atomic ticket counter.  (Measured with s_memrealtime: the second workgroup of each
+    // CU starts about 6 us after the first and runs about 30 % slower per tile -- the older waves win the
+    // arbitration -- so a static split left half of the chip idle for the last 20 us of the launch.)
+    // The ticket for the tile after `nxt` is requested before the MFMA loop by one lane, published through LDS
+    // behind the barrier that follows the loop, and returned to the caller.
+    auto process = [&](auto FIRST, int2 cur, f32x4 (&pv)[16], bool have_next, int2 nxt, f32x4 (&pn)[16]) -> int {
+        if (decltype(FIRST)::value)
+        {
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        }
+        else
+        {
+            __builtin_amdgcn_s_waitcnt(0x4F70); // vmcnt(16)
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (have_next)
+        {
+            load_tile(tile_base(nxt), pn);
+        }
+        // the ticket request is inline asm so that the compiler does not wait for its return value here (it
+        // would: a returning atomic inside a divergent branch is waited for at the join); it is collected after
+        // the MFMA loop behind an explicit vmcnt(0)
+        int tk_raw = 0;
+        if (have_next && tid == 0)
+        {
+            const int zero = 0, one = 1;
+            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_raw) : "v"(zero), "v"(one), "s"(ticket) : "memory");
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+        for (int kk = 0; kk < k8; kk += 8)
+        {
+#pragma unroll
+            for (int t = 0; t < 8; t += 2)
+            {
+                const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + t + lh) * 128 + 4 * lj]);
+                const float  a = sA[(kk + t + lh) * 128 + wave * 32 + lj];
+                acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+                acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+                acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+                acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+            }
+        }
+        // every wave has its operands in registers: the panels may be overwritten
+        if (tid == 0)
+        {
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the ticket has returned
+            asm volatile("" : "+v"(tk_raw));
+            s_next[0] = have_next ? 2 * G + tk_raw : ntiles;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): every LDS read (and the ticket write) of this wave is done
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int nn = __builtin_amdgcn_readfirstlane(s_next[0]);
+        if (have_next)
+        {
+            dma_panels(nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float* pbase = tile_base(cur);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            pv[r][0] -= acc0[r];
+            pv[r][1] -= acc1[r];
+            pv[r][2] -= acc2[r];
+            pv[r][3] -= acc3[r];
+            float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
+            if (NT)
+            {
+                __builtin_nontemporal_store(pv[r], reinterpret_cast<f32x4*>(dst));
+            }
+            else
+            {
+                *reinterpret_cast<f32x4*>(dst) = pv[r];
+            }
+        }
+        if (MIRROR && cur.x != cur.y)
+        {
+            float* mbase = P + (size_t)(cur.x * 128 + 4 * lj) * ldp + cur.y * 128 + wave * 32 + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                {
+                    const f32x4 m = {pv[4 * g + 0][b], pv[4 * g + 1][b], pv[4 * g + 2][b], pv[4 * g + 3][b]};
+                    *reinterpret_cast<f32x4*>(mbase + (size_t)b * ldp + 8 * g) = m;
+                }
+            }
+        }
+        return nn;
+    };
+
+    int t = blockIdx.x;
+    if (t == 0 && tid == 0)
+    {
+        *ticket_reset = 0; // the counter the NEXT launch on this stream will use
+    }
+    if (t >= ntiles)
+    {
+        return;
+    }
+    f32x4 pvA[16], pvB[16];
+    int2  cur = tile_of(t);
+    load_tile(tile_base(cur), pvA);
+    asm volatile("" ::: "memory"); // keep the requests here (their values are first used in the epilogue)
+    dma_panels(cur);
+    if (hwids != nullptr && tid == 0)
+    {
+        // diagnostics: HW_ID (hwreg 4) and XCC_ID (hwreg 20) of this workgroup's first wave
+        hwids[4 * blockIdx.x]     = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        hwids[4 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        hwids[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(); // 100 MHz, chip-wide
+    }
+    // Phase stagger: two workgroups share a CU and start together; left alone they run their MFMA loops at the
+    // same time (sharing the matrix pipe) and their memory phases at the same time (leaving it idle).  Delaying
+    // one of the two by about half a tile period makes them alternate.
+    const bool late = stagger_mode == 1 ? (blockIdx.x >= (unsigned)(G / 2))
+                    : stagger_mode == 2 ? (((blockIdx.x >> 3) & 1) != 0)
+                    : stagger_mode == 3 ? (((blockIdx.x >> 8) & 1) != 0)
+                                        : false;
+    if (late)
+    {
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        while ((long long)__builtin_readcyclecounter() - t0 < stagger_cycles)
+        {
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    int  tn  = t + G;
+    bool hn  = tn < ntiles;
+    int2 nxt = hn ? tile_of(tn) : cur;
+    int  nn  = process(std::true_type{}, cur, pvA, hn, nxt, pvB);
+    while (hn)
+    {
+        cur = nxt;
+        tn  = nn;
+        hn  = tn < ntiles;
+        nxt = hn ? tile_of(tn) : cur;
+        nn  = process(std::false_type{}, cur, pvB, hn, nxt, pvA);
+        if (!hn)
+        {
+            break;
+        }
+        cur = nxt;
+        tn  = nn;
+        hn  = tn < ntiles;
+        nxt = hn ? tile_of(tn) : cur;
+        nn  = process(std::false_type{}, cur, pvA, hn, nxt, pvB);
+    }
+    if (hwids != nullptr && tid == 0)
+    {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        hwids[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
