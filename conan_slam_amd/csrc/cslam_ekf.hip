@@ -37,7 +37,7 @@ struct EkfBase
     int         ldp      = 0; // padded leading dimension / column count
     int         n        = 3;
     int         sync_mode = 1;
-    int         tune_downdate = 0; // env CSLAM_TUNE_DOWNDATE: 0 shipped (persistent symmetric, pipelined for k<=64), 1 tile-per-workgroup full, 2 persistent symmetric unpipelined, 4 first version
+    int         tune_downdate = 0; // env CSLAM_TUNE_DOWNDATE: 0 shipped (persistent symmetric; k<=64: memory ops inside the MFMA loop), 1 tile-per-workgroup full, 2 persistent symmetric unpipelined, 3 pipelined across tiles only, 4 first version
     int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
     int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (readlane one-wave up to k=64, workgroup-parallel up to 128 in f32, general beyond), 2 general always, 3 workgroup-parallel always, 5 blocked 2x2 (f32, 32<k<=64)
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
@@ -1125,7 +1125,23 @@ int Ekf<float>::launch_downdate(const float* W, int k)
             // block-lower P that fits the 256 MB infinity cache is better served by ordinary (cached) accesses:
             // measured 94 vs 101 us at n = 10003 (207 MB); above that, streaming hints win
             const bool nt = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
-            if (lower && !nt)
+            if (lower && tune_downdate == 0 && ldp < 32768)
+            {
+                // every memory operation interleaved with the MFMA loop
+                if (nt)
+                {
+                    hipLaunchKernelGGL((ekf_downdate_psym4_f32<true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
+                                       dTiles, n_sym_tiles, dTicket + (launch_parity & 1),
+                                       dTicket + ((launch_parity + 1) & 1), dHwIds);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((ekf_downdate_psym4_f32<false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
+                                       dTiles, n_sym_tiles, dTicket + (launch_parity & 1),
+                                       dTicket + ((launch_parity + 1) & 1), dHwIds);
+                }
+            }
+            else if (lower && !nt)
             {
                 hipLaunchKernelGGL((ekf_downdate_psym3_f32<false, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
                                    tiles_built, n_sym_tiles, dTicket + (launch_parity & 1),
@@ -1359,14 +1375,14 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     }
     // Block-lower storage: only 128x128 tiles on/below the tile diagonal of the symmetric P are maintained
     // (the P-GEMM then writes each tile once).  Needs the persistent symmetric kernel -> f32 default path only.
-    b->lower = (dtype == CSLAM_F32 && (b->tune_downdate == 0 || b->tune_downdate == 2)) ? 1 : 0;
+    b->lower = (dtype == CSLAM_F32 && (b->tune_downdate == 0 || b->tune_downdate == 2 || b->tune_downdate == 3)) ? 1 : 0;
     if (const char* sv = getenv("CSLAM_STORAGE"))
     {
         if (!strcmp(sv, "full"))
         {
             b->lower = 0;
         }
-        else if (!strcmp(sv, "lower") && dtype == CSLAM_F32 && (b->tune_downdate == 0 || b->tune_downdate == 2))
+        else if (!strcmp(sv, "lower") && dtype == CSLAM_F32 && (b->tune_downdate == 0 || b->tune_downdate == 2 || b->tune_downdate == 3))
         {
             b->lower = 1;
         }

@@ -1596,6 +1596,236 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5 (f32), block-lower storage, k8 <= 64: the P-GEMM with every memory operation issued from INSIDE the MFMA
+// loop.  A pure read-modify-write of the same 3160 tiles (tools/probes/tile_rmw_probe.hip) takes 63 us; the
+// kernels above take 87-94 us because a wave's memory traffic comes in bursts between its MFMA loops (16 loads,
+// then 8200+ cycles of MFMA, then 16 stores): the memory system idles while the waves compute.  Here a tile's
+// k <= 64 is cut into two chunks of 32 (two pairs of LDS panel buffers, 16 KB each) and a wave's stream is
+//     chunk 0 of tile i : [barrier] DMA panels 1(i)   ; 16 k-pairs of MFMA; behind k-pairs 0-7 the 16 STORES of
+//                                                       tile i-1's results, behind 8-15 the first 8 LOADS of P_i
+//     chunk 1 of tile i : [wait panels 1, barrier] DMA panels 0(i+1) ; 16 k-pairs; behind 0-7 the other 8 LOADS
+//     P_i -= acc        (the results stay in registers until the next chunk 0)
+// One register set serves "results of tile i-1 going out" and "P_i coming in" (a load may overwrite a register
+// whose store has been issued: VMEM instructions leave in order), so the kernel needs acc (64) + P (64) VGPRs,
+// every tile runs the same code with the same register roles, and no tile waits for a store to complete.
+// All traffic uses buffer instructions (resource + uniform SGPR offset + one fixed per-lane VGPR offset): no
+// VGPRs hold 64-bit pointers.  Rows of W1 beyond k8 are outside the W1 resource: the DMA delivers zeros for them,
+// so every chunk is 32 deep and the MFMA loops have fixed trip counts.
+// vmcnt retires in order: "all but the 24 youngest" at the top of chunk 1 = the DMA issued at the top of chunk 0
+// has landed (16 stores + 8 loads were issued after it; 8 for a workgroup's first tile).
+// Tile hand-out by atomic ticket (see psym3); a ticket requested at the top of tile i is collected at the top of
+// tile i+1, its tile looked up, published through LDS at the top of chunk 1 of tile i+1 and consumed there.
+// ------------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
+                       const int2* __restrict__ tile_list, int ntiles, int* __restrict__ ticket,
+                       int* __restrict__ ticket_reset, unsigned long long* __restrict__ hwids)
+{
+    constexpr int KC = 32;
+    // four separate LDS objects (not one array): the compiler's wait-count pass can then tell that the panel
+    // DMA in flight (other chunk's buffers) does not alias the buffers the MFMA loop is reading
+    __shared__ __attribute__((aligned(16))) float s_b0[KC * 128]; // chunk 0: rows of the tile    [kk][128]
+    __shared__ __attribute__((aligned(16))) float s_a0[KC * 128]; // chunk 0: columns of the tile [kk][128]
+    __shared__ __attribute__((aligned(16))) float s_b1[KC * 128];
+    __shared__ __attribute__((aligned(16))) float s_a1[KC * 128];
+    __shared__ int2 s_next;
+
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lj   = lane & 31;
+    const int lh   = lane >> 5;
+    const int G    = gridDim.x;
+
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kAux = NT ? 2 : 0; // nt
+    // (P must be < 4 GiB: ldp < 32768; the host checks.)
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P, 0, (unsigned)((size_t)ldp * ldp * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W1), 0, (unsigned)((size_t)k8 * ldw * 4), 0x00020000);
+    const unsigned lane_off = (unsigned)(((wave * 32 + 4 * lh) * ldp + 4 * lj) * 4);
+    auto tile_base = [&](int2 t) -> unsigned { return (unsigned)(((size_t)(t.y * 128) * ldp + t.x * 128) * 4); };
+    auto row_off   = [&](int r) -> unsigned { return (unsigned)(((r & 3) + 8 * (r >> 2)) * ldp * 4); };
+    auto load1     = [&](unsigned tbase, int r) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, lane_off, tbase + row_off(r), kAux));
+    };
+    auto store1 = [&](unsigned tbase, int r, f32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsP, lane_off, tbase + row_off(r), kAux);
+    };
+    // panel chunk C (rows C*32 .. C*32+31 of W1) of tile t into the LDS buffers of chunk C: always 8 DMA
+    // instructions per wave (each: 2 rows x 128 floats)
+    const unsigned dma_lane_off = (unsigned)((lh * ldw + 4 * lj) * 4);
+    auto dma_chunk = [&](int2 t, auto C) {
+        constexpr int  c    = decltype(C)::value;
+        const unsigned row0 = (unsigned)(t.x * 128 * 4), col0 = (unsigned)(t.y * 128 * 4);
+#pragma unroll
+        for (int it = 0; it < KC / 8; it++)
+        {
+            const int      kkb  = it * 8 + wave * 2;
+            const unsigned roff = (unsigned)((c * KC + kkb) * ldw * 4);
+            lptr_t         db   = (lptr_t)((c == 0 ? s_b0 : s_b1) + kkb * 128);
+            lptr_t         da   = (lptr_t)((c == 0 ? s_a0 : s_a1) + kkb * 128);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, db, 16, dma_lane_off, roff + row0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, da, 16, dma_lane_off, roff + col0, 0, 0);
+        }
+    };
+
+    f32x16 acc0, acc1, acc2, acc3;
+    // one k-pair (4 MFMAs) of chunk C at rows g*2, g*2+1 (g = 0..15)
+    auto mfma_group = [&](auto C, int g) {
+        constexpr int c  = decltype(C)::value;
+        const float*  sB = c == 0 ? s_b0 : s_b1;
+        const float*  sA = c == 0 ? s_a0 : s_a1;
+        const float4  b  = *reinterpret_cast<const float4*>(&sB[(2 * g + lh) * 128 + 4 * lj]);
+        const float   a  = sA[(2 * g + lh) * 128 + wave * 32 + lj];
+        acc0             = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+        acc1             = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+        acc2             = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+        acc3             = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+
+    f32x4 pv[16]; // results of the previous tile -> P of the current tile -> results of the current tile
+
+    // One tile.  prev_base: where the results held in pv go (not FIRST).  t_next_in: FIRST: index of the next
+    // tile; otherwise thread 0's raw ticket from one tile ago.  Returns false after the workgroup's last tile.
+    auto process = [&](auto FIRST, int2 cur, unsigned cbase, unsigned prev_base, int t_next_in, int& t_next_out,
+                       int2& nxt_out) -> bool {
+        constexpr bool first = decltype(FIRST)::value;
+        // ---- chunk 0 ----  (its panels landed before the previous tile's subtraction; FIRST: wait here)
+        __builtin_amdgcn_s_waitcnt(first ? 0x0070 : 0xC07F); // FIRST: vmcnt(0); always lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        int2 look   = make_int2(-1, -1);
+        int  tk_new = 0;
+        if (tid == 0)
+        {
+            if (!first)
+            {
+                int tk_raw = t_next_in;
+                asm volatile("" : "+v"(tk_raw));
+                const int tt = 2 * G + tk_raw;
+                if (tt >= 0 && tt < ntiles)
+                {
+                    look = tile_list[tt];
+                }
+            }
+            const int zero = 0, one = 1;
+            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_new) : "v"(zero), "v"(one), "s"(ticket) : "memory");
+        }
+        dma_chunk(cur, C1{});
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = acc1 = acc2 = acc3 = f32x16{0};
+#pragma unroll
+        for (int g = 0; g < 16; g++)
+        {
+            mfma_group(C0{}, g);
+            if (g < 8)
+            {
+                if (!first)
+                {
+                    store1(prev_base, 2 * g, pv[2 * g]);
+                    store1(prev_base, 2 * g + 1, pv[2 * g + 1]);
+                }
+            }
+            else
+            {
+                pv[g - 8] = load1(cbase, g - 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- chunk 1 ----
+        __builtin_amdgcn_s_waitcnt(first ? 0x0F78 : 0x4F78); // vmcnt(8 | 24): the DMA above has landed
+        if (!first && tid == 0)
+        {
+            s_next = look;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        int2 nxt;
+        if (first)
+        {
+            nxt = t_next_in < ntiles ? tile_list[t_next_in] : make_int2(-1, -1);
+        }
+        else
+        {
+            const int2 sn = s_next;
+            nxt           = make_int2(__builtin_amdgcn_readfirstlane(sn.x), __builtin_amdgcn_readfirstlane(sn.y));
+        }
+        const bool have_next = nxt.x >= 0;
+        asm volatile("" : "+v"(tk_new)); // (its request has returned: covered by the wait above)
+        dma_chunk(have_next ? nxt : cur, C0{}); // (re-reads this tile's panel when there is no next tile: harmless)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 16; g++)
+        {
+            mfma_group(C1{}, g);
+            if (g < 8)
+            {
+                pv[g + 8] = load1(cbase, g + 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            pv[r][0] -= acc0[r];
+            pv[r][1] -= acc1[r];
+            pv[r][2] -= acc2[r];
+            pv[r][3] -= acc3[r];
+        }
+        t_next_out = tk_new; // raw ticket (valid in thread 0: its request has returned)
+        nxt_out    = nxt;
+        return have_next;
+    };
+
+    int t = blockIdx.x;
+    if (t == 0 && tid == 0)
+    {
+        *ticket_reset = 0; // the counter the NEXT launch on this stream will use
+    }
+    if (t >= ntiles)
+    {
+        return;
+    }
+    int2     cur   = tile_list[t];
+    unsigned cbase = tile_base(cur);
+    dma_chunk(cur, C0{});
+    if (hwids != nullptr && tid == 0)
+    {
+        hwids[4 * blockIdx.x]     = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        hwids[4 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        hwids[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+    int  tk = 0;
+    int2 nxt;
+    bool hn = process(std::true_type{}, cur, cbase, 0u, t + G, tk, nxt);
+    while (hn)
+    {
+        const unsigned rbase = cbase;
+        cur                  = nxt;
+        cbase                = tile_base(cur);
+        hn                   = process(std::false_type{}, cur, cbase, rbase, tk, tk, nxt);
+    }
+    // the last tile's results
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        store1(cbase, r, pv[r]);
+    }
+    if (hwids != nullptr && tid == 0)
+    {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        hwids[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block-lower storage -> full symmetric matrix (used by get_state): every tile above the tile diagonal is
 // filled with the transpose of its mirror.  32x32 sub-tiles through LDS so both sides are coalesced.
 // grid = (ceil(n/32), ceil(n/32)); blocks not strictly above the 128-tile diagonal exit.
