@@ -76,6 +76,8 @@ struct Ekf : EkfBase
     int  slot_col  = 0;   // first column of the last update's W1
     T*   dS    = nullptr;
     T*   dG    = nullptr;
+    T*   dSub  = nullptr; // (3 + 64) x 64 compact block of PHT (see ekf_gather_kernel)
+    bool sub_valid = false;
     T*   dGt   = nullptr;
     T*   dV    = nullptr;
     T*   dt_   = nullptr;
@@ -167,13 +169,14 @@ struct Ekf : EkfBase
         (void)hipFree(dPHT);
         (void)hipFree(dS);
         (void)hipFree(dG);
+        (void)hipFree(dSub);
         (void)hipFree(dGt);
         (void)hipFree(dV);
         (void)hipFree(dt_);
         (void)hipFree(dU);
         (void)hipFree(dScrS);
         (void)hipFree(dScrG);
-        dPHT = dS = dG = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
+        dPHT = dS = dG = dSub = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
     }
 
     int use_device() { CSLAM_HIP_TRY(hipSetDevice(device)); return CSLAM_OK; }
@@ -277,6 +280,10 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMalloc(&dPHT, pan));
         CSLAM_HIP_TRY(hipMalloc(&dS, kk));
         CSLAM_HIP_TRY(hipMalloc(&dG, kk));
+        if (dSub == nullptr)
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dSub, (size_t)(3 + 64) * 64 * sizeof(T)));
+        }
         CSLAM_HIP_TRY(hipMalloc(&dGt, kk));
         CSLAM_HIP_TRY(hipMalloc(&dScrS, kk));
         CSLAM_HIP_TRY(hipMalloc(&dScrG, kk));
@@ -623,6 +630,7 @@ struct Ekf : EkfBase
         a.scratchG = dScrG;
         a.textbook = (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1;
         a.stamps   = dStamps;
+        a.sub      = sub_valid ? dSub : nullptr;
         a.lds_S    = 1;
         a.lds_G    = 1;
         {
@@ -672,8 +680,28 @@ struct Ekf : EkfBase
         }
         if (k <= 64 && tune_factor != 2)
         {
-            // register-resident factorisation with v_readlane broadcasts (A/B: CSLAM_TUNE_FACTOR=1)
-            if (k <= 4)
+            bool launched = false;
+            if constexpr (std::is_same<T, float>::value)
+            {
+                // rank-1 updates on the matrix cores (A/B: CSLAM_TUNE_FACTOR=1 selects the readlane kernel)
+                if (k > 16 && tune_factor == 0)
+                {
+                    if (k <= 32)
+                    {
+                        hipLaunchKernelGGL((ekf_factor_mfma_f32<32>), dim3(1), dim3(256), 0, stream, a, dU);
+                    }
+                    else
+                    {
+                        hipLaunchKernelGGL((ekf_factor_mfma_f32<64>), dim3(1), dim3(256), 0, stream, a, dU);
+                    }
+                    launched = true;
+                }
+            }
+            // register-resident factorisation with v_readlane broadcasts
+            if (launched)
+            {
+            }
+            else if (k <= 4)
             {
                 hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
             }
@@ -690,6 +718,16 @@ struct Ekf : EkfBase
                 hipLaunchKernelGGL((ekf_factor_small_kernel<T, 64>), dim3(1), dim3(256), 0, stream, a, dU);
             }
             CSLAM_HIP_TRY(hipGetLastError());
+            if (dStamps && stamp_prints < 3)
+            {
+                long long h[16];
+                CSLAM_HIP_TRY(hipMemcpyAsync(h, dStamps, sizeof(h), hipMemcpyDeviceToHost, stream));
+                CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+                fprintf(stderr, "[cslam factor stamps, cycles] build S:%lld (observe %lld, sums %lld, symmetrise+store %lld) cholesky:%lld (first half %lld) inverse:%lld outputs:%lld (check %lld, G %lld, t/u %lld) total:%lld\n",
+                        h[1] - h[0], h[6] - h[0], h[7] - h[6], h[1] - h[7], h[2] - h[1], h[5] ? h[5] - h[1] : 0, h[3] - h[2],
+                        h[4] - h[3], h[8] - h[3], h[9] - h[8], h[4] - h[9], h[4] - h[0]);
+                stamp_prints++;
+            }
             return CSLAM_OK;
         }
         size_t mat   = (size_t)k * (k + 1) * sizeof(T);
@@ -752,7 +790,10 @@ struct Ekf : EkfBase
             return rc;
         }
         const dim3 ggrid((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs);
-        hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp, lower);
+        // the compact H-rows block for the MFMA factor kernel (f32, 16 < k <= 64, no pending panels to correct)
+        sub_valid = (sizeof(T) == 4 && k > 16 && k <= 64 && kp == 0 && tune_factor == 0 && dSub != nullptr);
+        hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp, lower,
+                           sub_valid ? dSub : nullptr);
         CSLAM_HIP_TRY(hipGetLastError());
         if (kp > 0) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T
         {

@@ -99,12 +99,21 @@ constexpr int kGatherObs = 8;
 template <typename T>
 __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X, const T* __restrict__ P, int ldp,
                                                           int n, const T* __restrict__ Z, const int* __restrict__ idf,
-                                                          int m, T* __restrict__ PHT, int ldw, int lower)
+                                                          int m, T* __restrict__ PHT, int ldw, int lower,
+                                                          T* __restrict__ sub = nullptr)
 {
+    // sub (optional, m <= 32): the (3 + 2m) x 2m block of PHT that S = H*PHT reads -- rows 0,1,2 and the two rows
+    // of every observed landmark -- stored compactly as sub[slot*2m + col] (slot 3+2o+a <-> row fx_o + a), so that
+    // the one-workgroup factor kernel loads 17 KB of contiguous data instead of 2000 scattered cache lines.
     __shared__ T   s_coef[kGatherObs * 10];
     __shared__ int s_fx[kGatherObs];
+    __shared__ int s_idf[32];
     int            o0 = blockIdx.y * kGatherObs;
     int            no = min(kGatherObs, m - o0);
+    if (sub != nullptr && (int)threadIdx.x < m && threadIdx.x < 32)
+    {
+        s_idf[threadIdx.x] = idf[threadIdx.x];
+    }
     if ((int)threadIdx.x < no)
     {
         T v[2];
@@ -118,6 +127,15 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         return;
     }
     T p0 = P[(size_t)0 * ldp + i], p1 = P[(size_t)1 * ldp + i], p2 = P[(size_t)2 * ldp + i];
+    unsigned hit = 0; // observations whose landmark owns row i
+    if (sub != nullptr && i >= 3)
+    {
+        const int lm1 = ((i - 3) >> 1) + 1; // 1-based landmark id of row i
+        for (int o = 0; o < m; o++)
+        {
+            hit |= (s_idf[o] == lm1) ? (1u << o) : 0u;
+        }
+    }
     for (int oo = 0; oo < no; oo++)
     {
         const T* c  = &s_coef[oo * 10];
@@ -138,6 +156,24 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         int col = 2 * (o0 + oo);
         PHT[(size_t)col * ldw + i]       = s0;
         PHT[(size_t)(col + 1) * ldw + i] = s1;
+        if (sub != nullptr)
+        {
+            const int k = 2 * m;
+            if (i < 3)
+            {
+                sub[i * k + col]     = s0;
+                sub[i * k + col + 1] = s1;
+            }
+            unsigned hh = hit;
+            while (hh)
+            {
+                const int o    = __builtin_ctz(hh);
+                const int slot = 3 + 2 * o + ((i - 3) & 1);
+                sub[slot * k + col]     = s0;
+                sub[slot * k + col + 1] = s1;
+                hh &= hh - 1;
+            }
+        }
     }
 }
 
@@ -347,6 +383,7 @@ struct FactorArgs
     T*         scratchS; // global k x (k+1) scratch used when LDS is too small
     T*         scratchG;
     long long* stamps; // diagnostic: s_memtime at phase boundaries (nullptr in production)
+    const T*   sub;    // compact (3+2m) x 2m block of PHT written by ekf_gather_kernel, or nullptr
     int        lds_S; // 1: S in LDS
     int        lds_G; // 1: G in LDS
     int        textbook;

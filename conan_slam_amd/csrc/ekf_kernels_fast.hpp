@@ -22,6 +22,7 @@ namespace cslam
 // wave-level broadcast of lane `src`'s value (src is a compile-time constant after unrolling)
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ inline float bcast(float v, int src)
 {
@@ -56,6 +57,13 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
     const int      k   = 2 * a.m;
     const int      tid = threadIdx.x;
 
+    auto stamp = [&](int i) {
+        if (a.stamps && tid == 0)
+        {
+            a.stamps[i] = (long long)__builtin_readcyclecounter();
+        }
+    };
+    stamp(0);
     if (tid == 0)
     {
         sflg[0] = 0;
@@ -155,6 +163,7 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
     }
     __syncthreads();
 
+    stamp(1);
     if (tid < 64) // ---------------- one wave: lane = row of S / column of inv(L)
     {
         const int lane = tid;
@@ -191,6 +200,7 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
                 }
             }
         }
+        stamp(2);
         // inv(L) by forward substitution, lane = column; L[r][q] is lane r's register q
         T    x[K];
         bool bad = false;
@@ -210,6 +220,7 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
             }
             bad = (__ballot(bad && lane < k) != 0ull);
         }
+        stamp(3);
         const bool zero = failed || bad;
         // G back into LDS (over S): REF_EXACT G = inv(L) -> G[r][c] = x[r] of lane c; TEXTBOOK G = inv(L)^T
         if (lane < K)
@@ -291,6 +302,448 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
             du[o] = s2;
         }
     }
+    stamp(4);
+    if (tid == 0)
+    {
+        const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
+        a.flags[1]     = code;
+        if (code)
+        {
+            atomicOr(&a.flags[0], code);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2+K3 (f32) for 16 < k <= 64 with the rank-1 updates of the Cholesky factorisation and of the triangular
+// inverse on the matrix cores.  Same inputs/outputs/flags as ekf_factor_small_kernel<float, K>.
+//
+// Why: in the register-resident kernel above every multiplier of a rank-1 update is broadcast with v_readlane
+// (8 issue cycles each, measured with tools/probes/issue_probe.hip: 12 cycles per element pair), 2016 pairs for
+// the factorisation and again for the inverse: 36k + 23k cycles at k = 64.  v_mfma_f32_32x32x2_f32 performs the
+// whole rank-1 update of a 32 x 32 tile in ONE instruction and needs no broadcast: its operands are vectors
+// spread over the lanes, and the pivot row of a symmetric matrix held in the accumulator layout is exactly that.
+//
+// Layout (wave 0 only; lane l: h = l>>5, c = l&31): tile T[I][J] is an f32x16 accumulator,
+//     T[I][J][r] of lane l  =  M[32 I + (r&3) + 8 (r>>2) + 4 h][32 J + c].
+// Row j of the matrix (j = 32 J' + jj) therefore sits in register rj = (jj&3) + 4 (jj>>3) of the lanes with
+// h = (jj>>2)&1, one column per lane: a ready-made MFMA operand (A[i = l&31][kslot = l>>5], B[kslot][c = l&31];
+// the other k-slot is fed zeros).  The matrix is kept fully symmetric (T01 is updated as well) so that row j is
+// column j.
+//   Cholesky step j:  d = M[j][j] (one v_readlane), rs = 1/sqrt(d), a = row_j * rs (= column j of L, masked to
+//                     rows >= j), L[:, j] -> LDS,  T -= a a^T  (3 MFMAs for j < 32, 1 for j >= 32)
+//   inverse step q:   X[q][:] = R[q][:] * rs_q -> G in LDS,  R -= L[:, q] X[q][:]  (R starts as I; 2 MFMAs)
+// 64 + 64 short dependent steps (~120 cycles each) instead of 2 x 2016 broadcast pairs.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, float* __restrict__ du)
+{
+    static_assert(K == 32 || K == 64, "one or two 32-wide tiles per dimension");
+    typedef float  T;
+    typedef float2 __attribute__((aligned(4))) float2_u; // landmark rows start at odd indices
+    constexpr int  LD = K + 1;
+    __shared__ T   S[K * LD];         // S, read once into accumulators
+    __shared__ T   Gm[K * LD + 128];  // X = inv(L): X[q][c] at q + c*LD; + scratch slots (lane + q)
+    __shared__ T   sub[(3 + K) * LD]; // the rows of PHT that H touches: 0,1,2, then fx_o, fx_o+1 per observation
+    __shared__ T   coef[(K / 2) * 10];
+    __shared__ T   V[K];
+    __shared__ T   tvec[K];
+    __shared__ int fxs[K / 2];
+    __shared__ int sflg[2];
+    const int      k   = 2 * a.m;
+    const int      tid = threadIdx.x;
+    auto stamp = [&](int i) {
+        if (a.stamps && tid == 0)
+        {
+            a.stamps[i] = (long long)__builtin_readcyclecounter();
+        }
+    };
+    stamp(0);
+    if (tid == 0)
+    {
+        sflg[0] = 0;
+        sflg[1] = 0;
+    }
+    if (tid < K)
+    {
+        V[tid] = (T)0;
+    }
+#pragma unroll
+    for (int it = 0; it < (K * LD + 255) / 256; it++)
+    {
+        const int e = tid + it * 256;
+        if (e < K * LD)
+        {
+            Gm[e] = (T)0;
+        }
+    }
+    // The rows of PHT that H touches.  Normal path: the compact block written by the gather kernel, contiguous and
+    // independent of the observation model (issued before it).  Without it (deferred downdates correct PHT after
+    // the gather): rows 0..2 here, the landmark rows after observe_model.
+    if (a.sub != nullptr)
+    {
+        constexpr int NS = ((3 + K) * K + 255) / 256;
+        T             sv[NS];
+#pragma unroll
+        for (int it = 0; it < NS; it++)
+        {
+            const int  e    = tid + it * 256;
+            const int  slot = e / K, c = e & (K - 1);
+            const bool in   = (slot < 3 + k) && (c < k);
+            sv[it]          = a.sub[in ? slot * k + c : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < NS; it++)
+        {
+            const int e    = tid + it * 256;
+            const int slot = e / K, c = e & (K - 1);
+            if (slot < 3 + K)
+            {
+                sub[slot * LD + c] = sv[it];
+            }
+        }
+    }
+    else if (tid < K && tid < k)
+    {
+        const T* p       = a.PHT + (size_t)tid * a.ldw;
+        sub[0 * LD + tid] = p[0];
+        sub[1 * LD + tid] = p[1];
+        sub[2 * LD + tid] = p[2];
+    }
+    __syncthreads();
+    for (int o = tid; o < a.m; o += 256)
+    {
+        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    __syncthreads();
+    stamp(6);
+    // the landmark rows: one 8-byte load per (observation, column) instead of two 4-byte loads per element of S
+    if (a.sub == nullptr)
+    {
+        constexpr int NP = (K / 2) * K / 256; // (o, c) pairs per thread
+        float2        pv[NP];
+#pragma unroll
+        for (int it = 0; it < NP; it++)
+        {
+            const int  e  = tid + it * 256;
+            const int  c  = e & (K - 1);
+            const int  o  = e / K;
+            const bool in = (o < a.m) && (c < k);
+            const int  fx = fxs[in ? o : 0];
+            pv[it]        = *reinterpret_cast<const float2_u*>(a.PHT + (size_t)(in ? c : 0) * a.ldw + fx);
+        }
+#pragma unroll
+        for (int it = 0; it < NP; it++)
+        {
+            const int e = tid + it * 256;
+            const int c = e & (K - 1);
+            const int o = e / K;
+            sub[(3 + 2 * o) * LD + c]     = pv[it].x;
+            sub[(3 + 2 * o + 1) * LD + c] = pv[it].y;
+        }
+    }
+    __syncthreads();
+    // S = H*PHT + RR (slam.h:244): 5-term sums in ascending column order; identity padding.
+    // A thread's 16 elements share the row r = tid & (K-1): its H coefficients are read once.
+    {
+        constexpr int NE = (K * K + 255) / 256;
+        const T       r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3];
+        const int     r   = tid & (K - 1);
+        const int     ob = r >> 1, ra = r & 1;
+        const bool    rin = r < k;
+        const T*      cf  = &coef[(rin ? ob : 0) * 10 + ra * 5];
+        const T       c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4];
+        const int     s3 = (3 + 2 * (rin ? ob : 0)) * LD;
+        // branch-free: all LDS reads of the 16 elements are issued first (clamped column), then the sums
+        T p0[NE], p1[NE], p2[NE], p3[NE], p4[NE];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int c  = (tid + it * 256) / K;
+            const int cc = (c < k) ? c : 0;
+            p0[it]       = sub[0 * LD + cc];
+            p1[it]       = sub[1 * LD + cc];
+            p2[it]       = sub[2 * LD + cc];
+            p3[it]       = sub[s3 + cc];
+            p4[it]       = sub[s3 + LD + cc];
+        }
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int c  = (tid + it * 256) / K;
+            T         sm = c0 * p0[it];
+            sm += c1 * p1[it];
+            sm += c2 * p2[it];
+            sm += c3 * p3[it];
+            sm += c4 * p4[it];
+            const int ri = ra + 2 * (c & 1);
+            const T   rv = (ri == 0) ? r00 : ((ri == 1) ? r10 : ((ri == 2) ? r01 : r11));
+            const T   vv = sm + (((c >> 1) == ob) ? rv : (T)0);
+            S[r + c * LD] = (rin && c < k) ? vv : ((r == c) ? (T)1 : (T)0);
+        }
+    }
+    __syncthreads();
+    stamp(7);
+    // makeSymmetric (slam.h:776-779): every thread owns 16 elements (r, c); it reads (r, c) and (c, r), then all
+    // write -- (x + y) * 0.5 is the same value from both sides
+    {
+        constexpr int NE = (K * K + 255) / 256;
+        T             sv[NE];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1);
+            const int c = e / K;
+            const T   x = S[r + c * LD], y = S[c + r * LD];
+            sv[it]      = (r > c) ? (x + y) * (T)0.5 : ((r < c) ? (y + x) * (T)0.5 : (x + x) * (T)0.5);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1);
+            const int c = e / K;
+            S[r + c * LD] = sv[it];
+            if (r < k && c < k)
+            {
+                a.dS[r + c * k] = sv[it];
+            }
+        }
+    }
+    __syncthreads();
+    stamp(1);
+
+    if (tid < 64) // ---------------- wave 0
+    {
+        const int lane  = tid;
+        const int h     = lane >> 5;
+        const int lc    = lane & 31;
+        const int trash = K * LD + lane;
+        f32x16    T00, T01, T11;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            T00[r]        = S[row + lc * LD];
+            if (K == 64)
+            {
+                T01[r] = S[row + (32 + lc) * LD];
+                T11[r] = S[32 + row + (32 + lc) * LD];
+            }
+        }
+        // Both loops are branch-free straight-line code (a failed pivot just lets NaNs run through: the flag
+        // zeroes the outputs afterwards), so the accumulators stay where the MFMAs leave them and each step reads
+        // one register per tile.  Measured (tools/probes/mfma_overlap_probe.hip): within ONE wave vector
+        // instructions do not overlap an MFMA in flight -- a step costs (MFMAs x 64 cycles) + (pivot chain, ~80
+        // cycles), whatever the order.  So the MFMA count is what is minimised: updates that the next pivot rows do
+        // not need (T11 during the first 32 steps; R10 likewise in the inverse) are deferred and applied two columns
+        // per MFMA (one per k-slot: the operands of a step live in one half of the wave, so the masked operands of a
+        // "half 0" step and a "half 1" step simply add).
+        bool failed = false;
+        T    rdiag[K]; // wave-uniform 1/L[j][j]
+        T    la0[32];  // column j of L, rows 0-31 (j < 32), as the masked MFMA operand; reused by the inverse
+        T    la1[K];   // column j of L, rows 32-63
+        auto halfof = [](int j) { return ((j & 31) >> 2) & 1; };
+        auto rowreg = [](int j) { return ((j & 31) & 3) + 4 * ((j & 31) >> 3); };
+        auto rowlo  = [&](int j) { return 32 * halfof(j) + (j & 31); };
+        auto on_ge  = [&](int j) { return (lane >= rowlo(j)) && (lane <= 32 * halfof(j) + 31); };
+        auto on_half = [&](int j) { return (lane >= 32 * halfof(j)) && (lane <= 32 * halfof(j) + 31); };
+        // the 16 (half-0 step, half-1 step) pairs of 0..31: p -> (8*(p>>2) + (p&3), that + 4)
+        auto pair_lo = [](int p) { return 8 * (p >> 2) + (p & 3); };
+        // ---- Cholesky (right-looking, symmetric storage) ----
+#pragma unroll
+        for (int j = 0; j < 32; j++)
+        {
+            const T dj = bcast(T00[rowreg(j)], rowlo(j));
+            failed     = failed || !(dj > (T)0);
+            const T rs = pivot_rsqrt(dj);
+            rdiag[j]   = rs;
+            const T a0 = on_ge(j) ? T00[rowreg(j)] * rs : (T)0; // L[lc][j]
+            la0[j]     = a0;
+            T00        = __builtin_amdgcn_mfma_f32_32x32x2f32(-a0, a0, T00, 0, 0, 0);
+            if (K == 64)
+            {
+                const T a1 = on_half(j) ? T01[rowreg(j)] * rs : (T)0; // L[32 + lc][j]
+                la1[j]     = a1;
+                T01        = __builtin_amdgcn_mfma_f32_32x32x2f32(-a0, a1, T01, 0, 0, 0);
+            }
+        }
+        if (K == 64)
+        {
+            stamp(5);
+            // T11 -= sum_{j<32} a1_j a1_j^T, two columns per MFMA
+#pragma unroll
+            for (int p = 0; p < 16; p++)
+            {
+                const T v = la1[pair_lo(p)] + la1[pair_lo(p) + 4];
+                T11       = __builtin_amdgcn_mfma_f32_32x32x2f32(-v, v, T11, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 32; j < K; j++)
+            {
+                const T dj = bcast(T11[rowreg(j)], rowlo(j));
+                failed     = failed || !(dj > (T)0);
+                const T rs = pivot_rsqrt(dj);
+                rdiag[j]   = rs;
+                const T a1 = on_ge(j) ? T11[rowreg(j)] * rs : (T)0; // L[32 + lc][j]
+                la1[j]     = a1;
+                if (j + 1 < K)
+                {
+                    T11 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a1, a1, T11, 0, 0, 0);
+                }
+            }
+        }
+        stamp(2);
+        // ---- inv(L): R = I, then for every q: X[q][:] = R[q][:] / L[q][q], R -= L[:, q] X[q][:] ----
+        // X[q][c] goes to Gm[q + c*LD] (the transposition for TEXTBOOK happens when G is read back); per-lane base
+        // addresses, one per half: lanes outside the half point at their scratch slot.  chk turns NaN as soon as
+        // one entry of X is not finite (0*Inf = NaN, 0*NaN = NaN): no compare in the loop.
+        T chk = (T)0;
+        {
+            f32x16 R00, R10, R11;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                R00[r]        = (row == lc) ? (T)1 : (T)0;
+                R10[r]        = (T)0;
+                R11[r]        = (row == lc) ? (T)1 : (T)0;
+            }
+            const int gA0 = (h == 0) ? lc * LD : trash, gA1 = (h == 0) ? (32 + lc) * LD : trash;
+            const int gB0 = (h == 1) ? lc * LD : trash, gB1 = (h == 1) ? (32 + lc) * LD : trash;
+            T         xs[32]; // rows 0..31 of X (cols 0-31), kept for the deferred R10 update
+#pragma unroll
+            for (int q = 0; q < 32; q++)
+            {
+                const T x0 = on_half(q) ? R00[rowreg(q)] * rdiag[q] : (T)0; // X[q][lc]  (zero for lc > q)
+                xs[q]      = x0;
+                chk        = __builtin_fmaf(x0, (T)0, chk);
+                Gm[(halfof(q) == 0 ? gA0 : gB0) + q] = x0;
+                if (q + 1 < 32)
+                {
+                    R00 = __builtin_amdgcn_mfma_f32_32x32x2f32(-la0[q], x0, R00, 0, 0, 0);
+                }
+            }
+            if (K == 64)
+            {
+                // R10 -= sum_{q<32} L[32.., q] X[q][:], two q per MFMA
+#pragma unroll
+                for (int p = 0; p < 16; p++)
+                {
+                    const T l = la1[pair_lo(p)] + la1[pair_lo(p) + 4];
+                    const T x = xs[pair_lo(p)] + xs[pair_lo(p) + 4];
+                    R10       = __builtin_amdgcn_mfma_f32_32x32x2f32(-l, x, R10, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 32; q < K; q++)
+                {
+                    const T x0 = on_half(q) ? R10[rowreg(q)] * rdiag[q] : (T)0; // X[q][lc]
+                    const T x1 = on_half(q) ? R11[rowreg(q)] * rdiag[q] : (T)0; // X[q][32 + lc]
+                    chk        = __builtin_fmaf(x0, (T)0, chk);
+                    chk        = __builtin_fmaf(x1, (T)0, chk);
+                    Gm[(halfof(q) == 0 ? gA0 : gB0) + q] = x0;
+                    Gm[(halfof(q) == 0 ? gA1 : gB1) + q] = x1;
+                    if (q + 1 < K)
+                    {
+                        R10 = __builtin_amdgcn_mfma_f32_32x32x2f32(-la1[q], x0, R10, 0, 0, 0);
+                        R11 = __builtin_amdgcn_mfma_f32_32x32x2f32(-la1[q], x1, R11, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        stamp(3);
+        const bool bad = (__ballot(!(chk == chk)) != 0ull);
+        if (lane == 0)
+        {
+            sflg[0] = failed ? 1 : 0;
+            sflg[1] = (!failed && bad) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    stamp(8);
+    const bool zero = (sflg[0] | sflg[1]) != 0;
+    if (zero) // LLT failure (slam.h:421-429 handled by the host in sync mode) or a non-finite inverse: G = 0
+    {
+#pragma unroll
+        for (int it = 0; it < (K * LD + 255) / 256; it++)
+        {
+            const int e = tid + it * 256;
+            if (e < K * LD)
+            {
+                Gm[e] = (T)0;
+            }
+        }
+        __syncthreads();
+    }
+    // outputs: G, G^T (coalesced), t = G^T V, u = G t.   G[r][c]: REF_EXACT G = inv(L) = X, TEXTBOOK G = X^T
+    const int gr = a.textbook ? LD : 1, gc = a.textbook ? 1 : LD;
+    {
+        constexpr int NE = (K * K + 255) / 256;
+        T             g1[NE], g2[NE];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int x = e & (K - 1), y = e / K;
+            g1[it]      = Gm[x * gr + y * gc]; // G[x][y]
+            g2[it]      = Gm[y * gr + x * gc]; // G[y][x]
+        }
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int x = e & (K - 1), y = e / K;
+            if (x < k && y < k)
+            {
+                a.dG[x + y * k]  = g1[it];
+                a.dGt[x + y * k] = g2[it]; // Gt[x][y] = G[y][x]
+            }
+        }
+    }
+    stamp(9);
+    {
+        const int o = tid >> 2, part = tid & 3; // 256 threads = 64 outputs x 4 parts
+        T         s = (T)0;
+        if (o < K)
+        {
+#pragma unroll 4
+            for (int r = part; r < K; r += 4)
+            {
+                s += Gm[r * gr + o * gc] * V[r]; // padding rows of V are zero
+            }
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0 && o < K)
+        {
+            if (o < k)
+            {
+                a.dt[o] = s;
+            }
+            tvec[o] = (o < k) ? s : (T)0;
+        }
+        __syncthreads();
+        T s2 = (T)0;
+        if (o < K)
+        {
+#pragma unroll 4
+            for (int c = part; c < K; c += 4)
+            {
+                s2 += Gm[o * gr + c * gc] * tvec[c];
+            }
+        }
+        s2 += __shfl_xor(s2, 1);
+        s2 += __shfl_xor(s2, 2);
+        if (part == 0 && o < k)
+        {
+            du[o] = s2;
+        }
+    }
+    stamp(4);
     if (tid == 0)
     {
         const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
