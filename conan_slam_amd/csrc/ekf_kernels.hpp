@@ -110,9 +110,10 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     __shared__ int s_idf[32];
     int            o0 = blockIdx.y * kGatherObs;
     int            no = min(kGatherObs, m - o0);
-    if (sub != nullptr && (int)threadIdx.x < m && threadIdx.x < 32)
+    __shared__ unsigned s_cand; // observations whose landmark rows fall into this block's 256 rows
+    if (sub != nullptr && threadIdx.x == 0)
     {
-        s_idf[threadIdx.x] = idf[threadIdx.x];
+        s_cand = 0u;
     }
     if ((int)threadIdx.x < no)
     {
@@ -121,6 +122,21 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         observe_model<T>(X, n, idf[o], Z[2 * o], Z[2 * o + 1], &s_coef[threadIdx.x * 10], v, &s_fx[threadIdx.x]);
     }
     __syncthreads();
+    if (sub != nullptr)
+    {
+        if ((int)threadIdx.x < m && threadIdx.x < 32)
+        {
+            const int id        = idf[threadIdx.x];
+            s_idf[threadIdx.x]  = id;
+            const int fxo       = 3 + 2 * id - 2; // first state row of that landmark
+            const int i0        = blockIdx.x * 256;
+            if (fxo + 1 >= i0 && fxo < i0 + 256)
+            {
+                atomicOr(&s_cand, 1u << threadIdx.x);
+            }
+        }
+        __syncthreads();
+    }
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n)
     {
@@ -131,9 +147,12 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     if (sub != nullptr && i >= 3)
     {
         const int lm1 = ((i - 3) >> 1) + 1; // 1-based landmark id of row i
-        for (int o = 0; o < m; o++)
+        unsigned  cc  = s_cand;
+        while (cc)
         {
+            const int o = __builtin_ctz(cc);
             hit |= (s_idf[o] == lm1) ? (1u << o) : 0u;
+            cc &= cc - 1;
         }
     }
     for (int oo = 0; oo < no; oo++)
