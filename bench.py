@@ -295,10 +295,17 @@ def main():
     dd_bytes = 2.0 * n * n * esize + 1.0 * n * k_launch * esize
     dd_flops = 2.0 * n * n * k_launch
     achieved = dd_bytes / dd_s / 1e9 if dd_s > 0 else None
+    tune_dd = os.environ.get("CSLAM_TUNE_DOWNDATE", "0")
     storage = "full" if (os.environ.get("CSLAM_STORAGE") == "full" or args.dtype == "f64" or
-                         os.environ.get("CSLAM_TUNE_DOWNDATE", "0") != "0") else "lower"
-    kernel_name = ("ekf_downdate_psym_f32<64,true,%s>" % ("false" if storage == "lower" else "true")
-                   if args.dtype == "f32" and os.environ.get("CSLAM_TUNE_DOWNDATE", "0") == "0" else "ekf_downdate_" + args.dtype)
+                         tune_dd not in ("0", "2", "3")) else "lower"
+    if args.dtype != "f32" or tune_dd in ("1", "4"):
+        kernel_name = "ekf_downdate_" + args.dtype
+    elif k_launch > 64 or tune_dd == "2":
+        kernel_name = "ekf_downdate_psym_f32<64,true,%s>" % ("false" if storage == "lower" else "true")
+    elif storage == "lower" and tune_dd == "0":
+        kernel_name = "ekf_downdate_psym4_f32<0>"   # memory operations inside the MFMA loop (the shipped path)
+    else:
+        kernel_name = "ekf_downdate_psym3_f32<%s>" % ("false,false" if storage == "lower" else "true,true")
     traffic = None  # physical HBM bytes per launch: from the committed rocprofv3 --pmc summary of this exact configuration
     try:
         for e in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]:

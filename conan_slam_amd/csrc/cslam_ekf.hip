@@ -1169,18 +1169,27 @@ int Ekf<float>::launch_downdate(const float* W, int k)
             if (lower && tune_downdate == 0 && ldp < 32768)
             {
                 // every memory operation interleaved with the MFMA loop
-                if (nt)
+                const int ntmode = psym_nt >= 0 ? psym_nt : (nt ? 1 : 0);
+#define CSLAM_LAUNCH_PSYM4(MODE)                                                                                    \
+    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8, dTiles,       \
+                       n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds)
+                if (ntmode == 1)
                 {
-                    hipLaunchKernelGGL((ekf_downdate_psym4_f32<true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                                       dTiles, n_sym_tiles, dTicket + (launch_parity & 1),
-                                       dTicket + ((launch_parity + 1) & 1), dHwIds);
+                    CSLAM_LAUNCH_PSYM4(1);
+                }
+                else if (ntmode == 2)
+                {
+                    CSLAM_LAUNCH_PSYM4(2);
+                }
+                else if (ntmode == 3)
+                {
+                    CSLAM_LAUNCH_PSYM4(3);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((ekf_downdate_psym4_f32<false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                                       dTiles, n_sym_tiles, dTicket + (launch_parity & 1),
-                                       dTicket + ((launch_parity + 1) & 1), dHwIds);
+                    CSLAM_LAUNCH_PSYM4(0);
                 }
+#undef CSLAM_LAUNCH_PSYM4
             }
             else if (lower && !nt)
             {

@@ -2069,7 +2069,8 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
 // Tile hand-out by atomic ticket (see psym3); a ticket requested at the top of tile i is collected at the top of
 // tile i+1, its tile looked up, published through LDS at the top of chunk 1 of tile i+1 and consumed there.
 // ------------------------------------------------------------------------------------------------
-template <bool NT>
+// NTMODE: 0 ordinary accesses, 1 non-temporal loads and stores, 2 loads only, 3 stores only
+template <int NTMODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
                        const int2* __restrict__ tile_list, int ntiles, int* __restrict__ ticket,
@@ -2093,7 +2094,8 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
 
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int kAux = NT ? 2 : 0; // nt
+    constexpr int kAuxLd = (NTMODE == 1 || NTMODE == 2) ? 2 : 0; // nt
+    constexpr int kAuxSt = (NTMODE == 1 || NTMODE == 3) ? 2 : 0;
     // (P must be < 4 GiB: ldp < 32768; the host checks.)
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P, 0, (unsigned)((size_t)ldp * ldp * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW =
@@ -2102,10 +2104,10 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
     auto tile_base = [&](int2 t) -> unsigned { return (unsigned)(((size_t)(t.y * 128) * ldp + t.x * 128) * 4); };
     auto row_off   = [&](int r) -> unsigned { return (unsigned)(((r & 3) + 8 * (r >> 2)) * ldp * 4); };
     auto load1     = [&](unsigned tbase, int r) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, lane_off, tbase + row_off(r), kAux));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, lane_off, tbase + row_off(r), kAuxLd));
     };
     auto store1 = [&](unsigned tbase, int r, f32x4 v) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsP, lane_off, tbase + row_off(r), kAux);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsP, lane_off, tbase + row_off(r), kAuxSt);
     };
     // panel chunk C (rows C*32 .. C*32+31 of W1) of tile t into the LDS buffers of chunk C: always 8 DMA
     // instructions per wave (each: 2 rows x 128 floats)

@@ -11,7 +11,9 @@ from collections import defaultdict
 def main():
     base = sys.argv[1]
     want = sys.argv[2] if len(sys.argv) > 2 else ""
-    for d in sorted(glob.glob(os.path.join(base, "*", "*"))):
+    for d in sorted(glob.glob(os.path.join(base, "*", "*")) + glob.glob(os.path.join(base, "*"))):
+        if not os.path.isdir(d):
+            continue
         cc = glob.glob(os.path.join(d, "*_counter_collection.csv"))
         kt = glob.glob(os.path.join(d, "*_kernel_trace.csv"))
         if not cc:
