@@ -99,6 +99,7 @@ struct Ekf : EkfBase
     long long* dStamps = nullptr; // CSLAM_FACTOR_STAMPS=1: in-kernel phase stamps of the factor kernel (diagnostic)
     int   stamp_prints = 0;
     long long* dPsymStamps = nullptr; // CSLAM_PSYM_STAMPS=1
+    int*       dPredictDone = nullptr; // block-completion counter of the fused predict kernel
     int*       dTicket     = nullptr; // two tile-ticket counters used alternately by successive P-GEMM launches
     unsigned   launch_parity = 0;
     int        psym_nt = -1; // CSLAM_PSYM_NT: non-temporal P accesses in the P-GEMM (-1: by footprint)
@@ -146,6 +147,7 @@ struct Ekf : EkfBase
         (void)hipFree(dPsymStamps);
         (void)hipFree(dHwIds);
         (void)hipFree(dTicket);
+        (void)hipFree(dPredictDone);
         (void)hipFree(dW1);
         (void)hipFree(dY);
         (void)hipFree(dTiles);
@@ -223,6 +225,8 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipMalloc(&dPsymStamps, 64 * sizeof(long long)));
             CSLAM_HIP_TRY(hipMemsetAsync(dPsymStamps, 0, 64 * sizeof(long long), stream));
         }
+        CSLAM_HIP_TRY(hipMalloc(&dPredictDone, sizeof(int)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPredictDone, 0, sizeof(int), stream));
         CSLAM_HIP_TRY(hipMalloc(&dTicket, 2 * sizeof(int)));
         CSLAM_HIP_TRY(hipMemsetAsync(dTicket, 0, 2 * sizeof(int), stream));
         if (const char* sv = getenv("CSLAM_PSYM_NT"))
@@ -591,15 +595,9 @@ struct Ekf : EkfBase
                                (T)dt, dW1, ldp, kp, fix_last);
             CSLAM_HIP_TRY(hipGetLastError());
         }
-        if (w > 0)
-        {
-            hipLaunchKernelGGL(ekf_predict_stripe_kernel<T>, dim3((w + 255) / 256), dim3(256), 0, stream, dX, dP, ldp,
-                               (T)v, (T)swa, (T)dt, w, lower);
-            CSLAM_HIP_TRY(hipGetLastError());
-        }
-        // Pvv and the pose (stripe width 0: the stripe was done above, reading the same old heading)
-        hipLaunchKernelGGL(ekf_predict_kernel<T>, dim3(1), dim3(64), 0, stream, dX, dP, ldp, n, (T)v, (T)swa, Q[0], Q[1],
-                           Q[2], Q[3], (T)wb, (T)dt, 0, lower);
+        // stripe on many CUs + Pvv/pose by the last block to finish, one launch (w = 0: one block, Pvv/pose only)
+        hipLaunchKernelGGL(ekf_predict_stripe_kernel<T>, dim3(std::max(1, (w + 255) / 256)), dim3(256), 0, stream, dX, dP,
+                           ldp, (T)v, (T)swa, Q[0], Q[1], Q[2], Q[3], (T)wb, (T)dt, std::max(w, 0), lower, dPredictDone);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }

@@ -2315,39 +2315,127 @@ __global__ void __launch_bounds__(256) ekf_mirror_upper_kernel(T* __restrict__ P
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6 split: (a) the cross-covariance stripe on many CUs (reads the old heading, writes only the stripe),
-// (b) a one-wave kernel for Pvv and the pose.  Stream order makes (b) see the old pose as (a) did.
+// K6 (EKF.cpp:406-455) in one launch: the cross-covariance stripe on many CUs (every block reads the old heading
+// and writes only the stripe), then the block that finishes LAST (atomic ticket) updates Pvv and the pose -- by
+// then every other block has consumed the old heading.  The ticket counter is reset by that block for the next
+// launch (launches on one stream are ordered).  Same arithmetic and summation order as ekf_predict_kernel.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) ekf_predict_stripe_kernel(const T* __restrict__ X, T* __restrict__ P, int ldp, T v,
-                                                                  T swa, T dt, int stripe_w, int lower)
+__global__ void __launch_bounds__(256) ekf_predict_stripe_kernel(T* __restrict__ X, T* __restrict__ P, int ldp, T v, T swa,
+                                                                  T q00, T q10, T q01, T q11, T wb, T dt, int stripe_w,
+                                                                  int lower, int* __restrict__ done)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= stripe_w)
+    __shared__ int s_last;
+    const int      j = blockIdx.x * 256 + threadIdx.x;
+    if (j < stripe_w)
+    {
+        const T phi = X[2];
+        const T g02 = -v * dt * dsin(swa + phi); // Gv = [[1,0,g02],[0,1,g12],[0,0,1]]  (EKF.cpp:419-428)
+        const T g12 = v * dt * dcos(swa + phi);
+        const int c  = 3 + j;
+        const T   a0 = p_sym<T>(P, ldp, 0, c, lower), a1 = p_sym<T>(P, ldp, 1, c, lower), a2 = p_sym<T>(P, ldp, 2, c, lower);
+        // rows of Gv * stripe in the dense summation order (zeros of Gv included)
+        T o0 = (T)1 * a0;
+        o0 += (T)0 * a1;
+        o0 += g02 * a2;
+        T o1 = (T)0 * a0;
+        o1 += (T)1 * a1;
+        o1 += g12 * a2;
+        T o2 = (T)0 * a0;
+        o2 += (T)0 * a1;
+        o2 += (T)1 * a2;
+        P[(size_t)c * ldp + 0] = o0;
+        P[(size_t)c * ldp + 1] = o1;
+        P[(size_t)c * ldp + 2] = o2;
+        P[(size_t)0 * ldp + c] = o0;
+        P[(size_t)1 * ldp + c] = o1;
+        P[(size_t)2 * ldp + c] = o2;
+    }
+    __syncthreads(); // every thread of this block has read the old heading (its value fed the stores above)
+    if (threadIdx.x == 0)
+    {
+        const int t = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last      = (t == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last == 0 || threadIdx.x != 0)
     {
         return;
     }
-    const T phi = X[2];
-    const T g02 = -v * dt * dsin(swa + phi); // Gv = [[1,0,g02],[0,1,g12],[0,0,1]]  (EKF.cpp:419-428)
-    const T g12 = v * dt * dcos(swa + phi);
-    const int c  = 3 + j;
-    const T   a0 = p_sym<T>(P, ldp, 0, c, lower), a1 = p_sym<T>(P, ldp, 1, c, lower), a2 = p_sym<T>(P, ldp, 2, c, lower);
-    // rows of Gv * stripe in the dense summation order (zeros of Gv included)
-    T o0 = (T)1 * a0;
-    o0 += (T)0 * a1;
-    o0 += g02 * a2;
-    T o1 = (T)0 * a0;
-    o1 += (T)1 * a1;
-    o1 += g12 * a2;
-    T o2 = (T)0 * a0;
-    o2 += (T)0 * a1;
-    o2 += (T)1 * a2;
-    P[(size_t)c * ldp + 0] = o0;
-    P[(size_t)c * ldp + 1] = o1;
-    P[(size_t)c * ldp + 2] = o2;
-    P[(size_t)0 * ldp + c] = o0;
-    P[(size_t)1 * ldp + c] = o1;
-    P[(size_t)2 * ldp + c] = o2;
+    *done = 0;
+    // Pvv = Gv Pvv Gv^T + Gu Q Gu^T and the pose (EKF.cpp:430-440, 445-452)
+    T phi = X[2];
+    T s = dsin(swa + phi), c = dcos(swa + phi);
+    T Gv[9] = {(T)1, (T)0, (T)0, (T)0, (T)1, (T)0, -v * dt * s, v * dt * c, (T)1}; // column-major
+    T Gu[6] = {dt * c, dt * s, dt * dsin(swa) / wb, -v * dt * s, v * dt * c, v * dt * dcos(swa) / wb};
+    T Q[4]  = {q00, q10, q01, q11};
+    T Pv[9], t1[9], t2[9], pvv[9];
+    for (int cc = 0; cc < 3; cc++)
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            Pv[r + 3 * cc] = P[(size_t)cc * ldp + r];
+        }
+    }
+    for (int cc = 0; cc < 3; cc++) // t1 = Gv*Pvv
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            for (int l = 0; l < 3; l++)
+            {
+                acc += Gv[r + 3 * l] * Pv[l + 3 * cc];
+            }
+            t1[r + 3 * cc] = acc;
+        }
+    }
+    for (int cc = 0; cc < 3; cc++) // t2 = t1*Gv^T
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            for (int l = 0; l < 3; l++)
+            {
+                acc += t1[r + 3 * l] * Gv[cc + 3 * l];
+            }
+            t2[r + 3 * cc] = acc;
+        }
+    }
+    T GuQ[6];
+    for (int cc = 0; cc < 2; cc++)
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            for (int l = 0; l < 2; l++)
+            {
+                acc += Gu[r + 3 * l] * Q[l + 2 * cc];
+            }
+            GuQ[r + 3 * cc] = acc;
+        }
+    }
+    for (int cc = 0; cc < 3; cc++)
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            for (int l = 0; l < 2; l++)
+            {
+                acc += GuQ[r + 3 * l] * Gu[cc + 3 * l];
+            }
+            pvv[r + 3 * cc] = t2[r + 3 * cc] + acc;
+        }
+    }
+    const T x0 = X[0] + v * dt * c;
+    const T x1 = X[1] + v * dt * s;
+    const T x2 = pi2pi<T>(X[2] + v * dt * dsin(swa) / wb);
+    for (int e = 0; e < 9; e++)
+    {
+        P[(size_t)(e / 3) * ldp + (e % 3)] = pvv[e];
+    }
+    X[0] = x0;
+    X[1] = x1;
+    X[2] = x2;
 }
 
 } // namespace cslam
