@@ -58,6 +58,8 @@ def parse_args():
                     help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = every update at once)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-deferred-extra", action="store_true",
+                    help="skip the additional deferred-mode measurement reported under 'deferred_mode'")
     ap.add_argument("--stage-profile", action="store_true", help="extra untimed pass with events around every stage")
     return ap.parse_args()
 
@@ -215,6 +217,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
 
     total_steps = args.warmup + args.steps
+    # second, clearly labelled measurement on the default line: the same steps with cslam_ekf_set_deferred(128)
+    with_deferred_extra = (world == 1 and args.defer == 0 and not args.sequential and args.dtype == "f32"
+                           and not args.no_deferred_extra)
+    extra_steps = args.steps if with_deferred_extra else 0
     w = Workload(args.landmarks, args.obs, dtype, seed=rank)
     n, m, k = w.n, args.obs, 2 * args.obs
     quirks = Q_TEXTBOOK if args.quirks == "textbook" else Q_REF_EXACT
@@ -226,9 +232,9 @@ def main():
 
     # inputs of every step, generated up front and made resident in HBM
     ctrl = []
-    Zall = np.zeros((total_steps, 2 * m), dtype=dtype)
-    Iall = np.zeros((total_steps, m), dtype=np.int32)
-    for t in range(total_steps):
+    Zall = np.zeros((total_steps + extra_steps, 2 * m), dtype=dtype)
+    Iall = np.zeros((total_steps + extra_steps, m), dtype=np.int32)
+    for t in range(total_steps + extra_steps):
         ctrl.append(w.controls(t))
         Z, idf = w.observations(t)
         Zall[t] = Z.reshape(-1, order="F")
@@ -280,6 +286,32 @@ def main():
         st = eng.stage_times()
         eng.set_profiling(0)
         stage_profile = {name: (ms / max(cnt, 1)) * 1e3 for name, (ms, cnt) in st.items()}  # us per launch
+
+    deferred_extra = None
+    if with_deferred_extra:
+        # the engine's deferred-downdate mode (P = Ps - Wp Wp^T, one P-GEMM per 128 pending columns = 2 steps here):
+        # same kernels otherwise, final flush inside the timed region, the filter simply continues
+        eng.set_deferred(128)
+        eng.set_profiling(2)
+        barrier()
+        t1 = time.perf_counter()
+        for t in range(total_steps, total_steps + extra_steps):
+            step(t)
+        eng.flush()
+        eng.synchronize()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        st2 = eng.stage_times()
+        eng.set_profiling(0)
+        eng.set_deferred(0)
+        d_ms, d_cnt = st2["downdate"]
+        deferred_extra = {
+            "value": extra_steps / el2, "unit": "update steps/s", "ms_per_step": el2 / extra_steps * 1e3,
+            "deferred_columns": 128, "p_gemm_launches": d_cnt, "p_gemm_launch_us": d_ms / max(d_cnt, 1) * 1e3,
+            "factor_flags": eng.factor_status(),
+            "note": "cslam_ekf_set_deferred(128): every update is applied (state, and covariance through the pending-panel "
+                    "correction); the P-GEMM runs once per 128 pending W1 columns; final flush inside the timed region",
+        }
 
     if rank != 0:
         eng.close()
@@ -358,6 +390,7 @@ def main():
             "mfma_frac_of_peak": (dd_flops / dd_s / 1e12 / MFMA_PEAK_TF[args.dtype]) if dd_s > 0 else None,
         },
         "factor_flags": flags,
+        "deferred_mode": deferred_extra,
         "trace_P_end": trace_end,
     }
     if stage_profile:

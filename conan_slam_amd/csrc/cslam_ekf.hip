@@ -1157,39 +1157,34 @@ int Ekf<float>::launch_downdate(const float* W, int k)
             return rc;
         }
         const int G = std::min(n_sym_tiles, 2 * num_cus);
-        if (k8 <= 64 && tune_downdate != 2)
+        if (k8 <= 128 && lower && tune_downdate == 0 && ldp < 32768)
+        {
+            // every memory operation interleaved with the MFMA loop; two (k <= 64) or four (k <= 128) chunks of 32
+            launch_parity++;
+            const bool nt     = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
+            const int  ntmode = psym_nt >= 0 ? psym_nt : (nt ? 1 : 0);
+#define CSLAM_LAUNCH_PSYM4(MODE, NCH)                                                                               \
+    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE, NCH>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8, dTiles,  \
+                       n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds)
+            if (k8 <= 64)
+            {
+                if (ntmode == 1) { CSLAM_LAUNCH_PSYM4(1, 2); }
+                else if (ntmode == 2) { CSLAM_LAUNCH_PSYM4(2, 2); }
+                else if (ntmode == 3) { CSLAM_LAUNCH_PSYM4(3, 2); }
+                else { CSLAM_LAUNCH_PSYM4(0, 2); }
+            }
+            else
+            {
+                if (ntmode == 1) { CSLAM_LAUNCH_PSYM4(1, 4); }
+                else { CSLAM_LAUNCH_PSYM4(0, 4); }
+            }
+#undef CSLAM_LAUNCH_PSYM4
+        }
+        else if (k8 <= 64 && tune_downdate != 2)
         {
             launch_parity++;
-            // software-pipelined across tiles (one panel chunk per tile)
-            // block-lower P that fits the 256 MB infinity cache is better served by ordinary (cached) accesses:
-            // measured 94 vs 101 us at n = 10003 (207 MB); above that, streaming hints win
             const bool nt = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
-            if (lower && tune_downdate == 0 && ldp < 32768)
-            {
-                // every memory operation interleaved with the MFMA loop
-                const int ntmode = psym_nt >= 0 ? psym_nt : (nt ? 1 : 0);
-#define CSLAM_LAUNCH_PSYM4(MODE)                                                                                    \
-    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8, dTiles,       \
-                       n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds)
-                if (ntmode == 1)
-                {
-                    CSLAM_LAUNCH_PSYM4(1);
-                }
-                else if (ntmode == 2)
-                {
-                    CSLAM_LAUNCH_PSYM4(2);
-                }
-                else if (ntmode == 3)
-                {
-                    CSLAM_LAUNCH_PSYM4(3);
-                }
-                else
-                {
-                    CSLAM_LAUNCH_PSYM4(0);
-                }
-#undef CSLAM_LAUNCH_PSYM4
-            }
-            else if (lower && !nt)
+            if (lower && !nt)
             {
                 hipLaunchKernelGGL((ekf_downdate_psym3_f32<false, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
                                    tiles_built, n_sym_tiles, dTicket + (launch_parity & 1),

@@ -340,7 +340,10 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
 {
     static_assert(K == 32 || K == 64, "one or two 32-wide tiles per dimension");
     typedef float  T;
-    typedef float2 __attribute__((aligned(4))) float2_u; // landmark rows start at odd indices
+    struct alignas(4) float2_u // landmark rows start at odd indices: an 8-byte load with 4-byte alignment
+    {
+        float x, y;
+    };
     constexpr int  LD = K + 1;
     __shared__ T   S[K * LD];         // S, read once into accumulators
     __shared__ T   Gm[K * LD + 128];  // X = inv(L): X[q][c] at q + c*LD; + scratch slots (lane + q)
@@ -432,7 +435,8 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
             const int  o  = e / K;
             const bool in = (o < a.m) && (c < k);
             const int  fx = fxs[in ? o : 0];
-            pv[it]        = *reinterpret_cast<const float2_u*>(a.PHT + (size_t)(in ? c : 0) * a.ldw + fx);
+            const float2_u q = *reinterpret_cast<const float2_u*>(a.PHT + (size_t)(in ? c : 0) * a.ldw + fx);
+            pv[it]           = make_float2(q.x, q.y);
         }
 #pragma unroll
         for (int it = 0; it < NP; it++)
@@ -2070,7 +2074,9 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
 // tile i+1, its tile looked up, published through LDS at the top of chunk 1 of tile i+1 and consumed there.
 // ------------------------------------------------------------------------------------------------
 // NTMODE: 0 ordinary accesses, 1 non-temporal loads and stores, 2 loads only, 3 stores only
-template <int NTMODE>
+// NCH: chunks of 32 columns per tile (2: k <= 64; 4: k <= 128, the deferred flushes).  Chunk c uses LDS buffer pair
+// c & 1; the stores go behind chunk 0, the loads behind chunk 0/1 (NCH = 2) or chunks 1 and 2 (NCH = 4).
+template <int NTMODE, int NCH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
                        const int2* __restrict__ tile_list, int ntiles, int* __restrict__ ticket,
@@ -2112,7 +2118,7 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
     // panel chunk C (rows C*32 .. C*32+31 of W1) of tile t into the LDS buffers of chunk C: always 8 DMA
     // instructions per wave (each: 2 rows x 128 floats)
     const unsigned dma_lane_off = (unsigned)((lh * ldw + 4 * lj) * 4);
-    auto dma_chunk = [&](int2 t, auto C) {
+    auto dma_chunk = [&](int2 t, auto C) { // C: chunk index (compile time); LDS buffer pair C & 1
         constexpr int  c    = decltype(C)::value;
         const unsigned row0 = (unsigned)(t.x * 128 * 4), col0 = (unsigned)(t.y * 128 * 4);
 #pragma unroll
@@ -2120,28 +2126,32 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
         {
             const int      kkb  = it * 8 + wave * 2;
             const unsigned roff = (unsigned)((c * KC + kkb) * ldw * 4);
-            lptr_t         db   = (lptr_t)((c == 0 ? s_b0 : s_b1) + kkb * 128);
-            lptr_t         da   = (lptr_t)((c == 0 ? s_a0 : s_a1) + kkb * 128);
+            lptr_t         db   = (lptr_t)(((c & 1) == 0 ? s_b0 : s_b1) + kkb * 128);
+            lptr_t         da   = (lptr_t)(((c & 1) == 0 ? s_a0 : s_a1) + kkb * 128);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, db, 16, dma_lane_off, roff + row0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, da, 16, dma_lane_off, roff + col0, 0, 0);
         }
     };
 
     f32x16 acc0, acc1, acc2, acc3;
-    // one k-pair (4 MFMAs) of chunk C at rows g*2, g*2+1 (g = 0..15)
-    auto mfma_group = [&](auto C, int g) {
-        constexpr int c  = decltype(C)::value;
-        const float*  sB = c == 0 ? s_b0 : s_b1;
-        const float*  sA = c == 0 ? s_a0 : s_a1;
-        const float4  b  = *reinterpret_cast<const float4*>(&sB[(2 * g + lh) * 128 + 4 * lj]);
-        const float   a  = sA[(2 * g + lh) * 128 + wave * 32 + lj];
-        acc0             = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
-        acc1             = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
-        acc2             = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
-        acc3             = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
+    // one k-pair (4 MFMAs) of the chunk in LDS buffer pair B at rows g*2, g*2+1 (g = 0..15)
+    auto mfma_group = [&](auto B, int g) {
+        constexpr int bsel = decltype(B)::value;
+        const float*  sB   = bsel == 0 ? s_b0 : s_b1;
+        const float*  sA   = bsel == 0 ? s_a0 : s_a1;
+        const float4  b    = *reinterpret_cast<const float4*>(&sB[(2 * g + lh) * 128 + 4 * lj]);
+        const float   a    = sA[(2 * g + lh) * 128 + wave * 32 + lj];
+        acc0               = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+        acc1               = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+        acc2               = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
+        acc3               = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
     };
     using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
+    // schedule of the 16 P loads of a tile over its chunks: NCH = 2: chunk 0 k-pairs 8-15 and chunk 1 k-pairs 0-7;
+    // NCH = 4: chunk 1 and chunk 2, k-pairs 0-7 (chunk 0 carries the 16 stores, the last chunk nothing)
+    constexpr int kLoadChunkA = (NCH == 2) ? 0 : 1; // loads 0-7
+    constexpr int kLoadChunkB = (NCH == 2) ? 1 : 2; // loads 8-15
+    constexpr int kLoadA_g0   = (NCH == 2) ? 8 : 0; // first k-pair behind which loads 0-7 go
 
     f32x4 pv[16]; // results of the previous tile -> P of the current tile -> results of the current tile
 
@@ -2150,80 +2160,106 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
     auto process = [&](auto FIRST, int2 cur, unsigned cbase, unsigned prev_base, int t_next_in, int& t_next_out,
                        int2& nxt_out) -> bool {
         constexpr bool first = decltype(FIRST)::value;
-        // ---- chunk 0 ----  (its panels landed before the previous tile's subtraction; FIRST: wait here)
-        __builtin_amdgcn_s_waitcnt(first ? 0x0070 : 0xC07F); // FIRST: vmcnt(0); always lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        int2 look   = make_int2(-1, -1);
-        int  tk_new = 0;
-        if (tid == 0)
-        {
-            if (!first)
+        int2           look   = make_int2(-1, -1);
+        int            tk_new = 0;
+        int2           nxt    = make_int2(-1, -1);
+        bool           have_next = false;
+        auto chunk = [&](auto CC) {
+            constexpr int c = decltype(CC)::value;
+            // VM operations issued behind the panel DMA at the top of chunk x ("all but that many" = the DMA landed)
+            constexpr int nb_prev = (c == 0) ? ((NCH - 1 == kLoadChunkA ? 8 : 0) + (NCH - 1 == kLoadChunkB ? 8 : 0))
+                                             : ((c - 1 == 0 && !first ? 16 : 0) + (c - 1 == kLoadChunkA ? 8 : 0) +
+                                                (c - 1 == kLoadChunkB ? 8 : 0));
+            // ---- top of chunk c: its panels have landed; everybody is done with the other buffer pair ----
+            if constexpr (c == 0)
             {
-                int tk_raw = t_next_in;
-                asm volatile("" : "+v"(tk_raw));
-                const int tt = 2 * G + tk_raw;
-                if (tt >= 0 && tt < ntiles)
-                {
-                    look = tile_list[tt];
-                }
+                // panels 0 were requested at the top of the previous tile's last chunk; whatever followed them (the
+                // loads of the subtraction) has been waited for, unless nothing followed (NCH = 4) or this is the
+                // first tile
+                __builtin_amdgcn_s_waitcnt((first || nb_prev == 0) ? 0x0070 : 0xC07F);
             }
-            const int zero = 0, one = 1;
-            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_new) : "v"(zero), "v"(one), "s"(ticket) : "memory");
-        }
-        dma_chunk(cur, C1{});
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = acc1 = acc2 = acc3 = f32x16{0};
-#pragma unroll
-        for (int g = 0; g < 16; g++)
-        {
-            mfma_group(C0{}, g);
-            if (g < 8)
+            else
             {
-                if (!first)
+                __builtin_amdgcn_s_waitcnt(nb_prev == 0 ? 0x0F70 : (nb_prev == 8 ? 0x0F78 : (nb_prev == 16 ? 0x4F70 : 0x4F78)));
+                if (c == 1 && !first && tid == 0)
+                {
+                    s_next = look;
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (c == 0)
+            {
+                // thread 0: the ticket requested one tile ago has returned (it is older than the DMA group waited for
+                // above): look its tile up (8-byte load, again covered by the next wait), then request the next one
+                if (tid == 0)
+                {
+                    if (!first)
+                    {
+                        int tk_raw = t_next_in;
+                        asm volatile("" : "+v"(tk_raw));
+                        const int tt = 2 * G + tk_raw;
+                        if (tt >= 0 && tt < ntiles)
+                        {
+                            look = tile_list[tt];
+                        }
+                    }
+                    const int zero = 0, one = 1;
+                    asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_new) : "v"(zero), "v"(one), "s"(ticket) : "memory");
+                }
+                acc0 = acc1 = acc2 = acc3 = f32x16{0};
+            }
+            if constexpr (c == 1)
+            {
+                if (first)
+                {
+                    nxt = t_next_in < ntiles ? tile_list[t_next_in] : make_int2(-1, -1);
+                }
+                else
+                {
+                    const int2 sn = s_next;
+                    nxt           = make_int2(__builtin_amdgcn_readfirstlane(sn.x), __builtin_amdgcn_readfirstlane(sn.y));
+                }
+                have_next = nxt.x >= 0;
+                asm volatile("" : "+v"(tk_new)); // (its request has returned: covered by the wait above)
+            }
+            // the next panels into the other buffer pair
+            if constexpr (c + 1 < NCH)
+            {
+                dma_chunk(cur, std::integral_constant<int, c + 1>{});
+            }
+            else
+            {
+                dma_chunk(have_next ? nxt : cur, C0{}); // (re-reads this tile's panel after the last tile: harmless)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 16; g++)
+            {
+                mfma_group(std::integral_constant<int, (c & 1)>{}, g);
+                if (c == 0 && g < 8 && !first)
                 {
                     store1(prev_base, 2 * g, pv[2 * g]);
                     store1(prev_base, 2 * g + 1, pv[2 * g + 1]);
                 }
+                if (c == kLoadChunkA && g >= kLoadA_g0 && g < kLoadA_g0 + 8)
+                {
+                    pv[g - kLoadA_g0] = load1(cbase, g - kLoadA_g0);
+                }
+                if (c == kLoadChunkB && g < 8)
+                {
+                    pv[g + 8] = load1(cbase, g + 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            else
-            {
-                pv[g - 8] = load1(cbase, g - 8);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- chunk 1 ----
-        __builtin_amdgcn_s_waitcnt(first ? 0x0F78 : 0x4F78); // vmcnt(8 | 24): the DMA above has landed
-        if (!first && tid == 0)
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        if constexpr (NCH == 4)
         {
-            s_next = look;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        int2 nxt;
-        if (first)
-        {
-            nxt = t_next_in < ntiles ? tile_list[t_next_in] : make_int2(-1, -1);
-        }
-        else
-        {
-            const int2 sn = s_next;
-            nxt           = make_int2(__builtin_amdgcn_readfirstlane(sn.x), __builtin_amdgcn_readfirstlane(sn.y));
-        }
-        const bool have_next = nxt.x >= 0;
-        asm volatile("" : "+v"(tk_new)); // (its request has returned: covered by the wait above)
-        dma_chunk(have_next ? nxt : cur, C0{}); // (re-reads this tile's panel when there is no next tile: harmless)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 16; g++)
-        {
-            mfma_group(C1{}, g);
-            if (g < 8)
-            {
-                pv[g + 8] = load1(cbase, g + 8);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            chunk(std::integral_constant<int, 2>{});
+            chunk(std::integral_constant<int, 3>{});
         }
         asm volatile("" ::: "memory");
 #pragma unroll
