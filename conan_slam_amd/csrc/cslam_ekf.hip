@@ -52,6 +52,7 @@ struct EkfBase
     virtual int update(const void* Z, int m, const void* R, const int* idf, int batch, bool on_device) = 0;
     virtual int augment(const void* Z, int q, const void* R)                                   = 0;
     virtual int observe_heading(double phi, int use)                                           = 0;
+    virtual int associate(const void* Z, int m, const void* R, double g1, double g2, int* idf_out, int* kind) = 0;
     virtual int factor_status(int* flags, int clear)                                           = 0;
     virtual int set_profiling(int on)                                                          = 0;
     virtual int get_stage_times(double* ms, int* launches)                                     = 0;
@@ -148,6 +149,8 @@ struct Ekf : EkfBase
         (void)hipFree(dHwIds);
         (void)hipFree(dTicket);
         (void)hipFree(dPredictDone);
+        (void)hipFree(dAssoc);
+        (void)hipFree(dAssocOut);
         (void)hipFree(dW1);
         (void)hipFree(dY);
         (void)hipFree(dTiles);
@@ -567,6 +570,66 @@ struct Ekf : EkfBase
             ms[s] += (double)t;
             launches[s] += 1;
         }
+        return CSLAM_OK;
+    }
+
+    // ---------------------------------------------------------------- data association (EKF.cpp:131-144, 235-326)
+    T*   dAssoc    = nullptr; // 8 scalars per feature
+    int  assoc_cap = 0;
+    int* dAssocOut = nullptr; // idf[m], kind[m]
+    int  assoc_mcap = 0;
+    int associate(const void* Zv, int m, const void* Rv, double g1, double g2, int* idf_out, int* kind_out) override
+    {
+        if (m < 0 || !Rv || (m > 0 && (!Zv || !idf_out || !kind_out)))
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "associate: bad arguments (m=%d)", m);
+        }
+        if (m == 0)
+        {
+            return CSLAM_OK;
+        }
+        int rc = use_device();
+        if (rc || (rc = flush()))
+        {
+            return rc;
+        }
+        const int nf = (n - 3) / 2;
+        if (nf > assoc_cap)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(dAssoc);
+            dAssoc = nullptr;
+            CSLAM_HIP_TRY(hipMalloc(&dAssoc, (size_t)std::max(nf, 1) * 8 * sizeof(T)));
+            assoc_cap = nf;
+        }
+        if (m > assoc_mcap)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(dAssocOut);
+            dAssocOut = nullptr;
+            CSLAM_HIP_TRY(hipMalloc(&dAssocOut, (size_t)2 * m * sizeof(int)));
+            assoc_mcap = m;
+        }
+        const T* R  = static_cast<const T*>(Rv);
+        const T* dZ = nullptr;
+        const int* dummy = nullptr;
+        std::vector<int> zero_idf((size_t)m, 1);
+        if ((rc = stage_obs(Zv, zero_idf.data(), m, &dZ, &dummy)))
+        {
+            return rc;
+        }
+        if (nf > 0)
+        {
+            hipLaunchKernelGGL(ekf_assoc_feature_kernel<T>, dim3((nf + 255) / 256), dim3(256), 0, stream, dX, dP, ldp, n,
+                               R[0], R[1], R[2], R[3], lower, dAssoc);
+            CSLAM_HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(ekf_assoc_scan_kernel<T>, dim3(m), dim3(64), 0, stream, dAssoc, nf, dZ, m, (T)g1, (T)g2,
+                           dAssocOut, dAssocOut + m);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipMemcpyAsync(idf_out, dAssocOut, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipMemcpyAsync(kind_out, dAssocOut + m, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         return CSLAM_OK;
     }
 
@@ -1535,6 +1598,13 @@ int cslam_ekf_augment(cslam_ekf_t h, const void* Z, int q, const void* R)
 {
     CSLAM_NEED(h);
     return B(h)->augment(Z, q, R);
+}
+
+int cslam_ekf_associate(cslam_ekf_t h, const void* Z, int m, const void* R, double gate1, double gate2, int* idf_out,
+                        int* kind_out)
+{
+    CSLAM_NEED(h);
+    return B(h)->associate(Z, m, R, gate1, gate2, idf_out, kind_out);
 }
 
 int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading)

@@ -13,6 +13,10 @@ constexpr double kPi = 3.14159265358979323846264338327950288; // the reference's
 // ------------------------------------------------------------------------------------------------
 __device__ inline float  dsqrt(float x) { return sqrtf(x); }
 __device__ inline double dsqrt(double x) { return sqrt(x); }
+__device__ inline float  dabs(float x) { return fabsf(x); }
+__device__ inline double dabs(double x) { return fabs(x); }
+__device__ inline float  dlog(float x) { return logf(x); }
+__device__ inline double dlog(double x) { return log(x); }
 __device__ inline float  datan2(float y, float x) { return atan2f(y, x); }
 __device__ inline double datan2(double y, double x) { return atan2(y, x); }
 __device__ inline float  dsin(float x) { return sinf(x); }

@@ -197,6 +197,172 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gated nearest-neighbour data association (EKF.cpp:131-144 computeAssociation, EKF.cpp:235-326 dataAssociate).
+// The reference evaluates S = H P H^T + R, its inverse and determinant for every (observation, feature) pair,
+// but S, inv(S), det(S) and the predicted observation depend on the FEATURE only:
+//   ekf_assoc_feature_kernel : one lane per feature j: the 5 x 5 block of P that H_j touches -> S_j (dense summation
+//                              order: (H*P) first, then (H*P)*H^T, structural zeros add nothing), 2 x 2 partially
+//                              pivoted LU inverse and determinant (what Eigen's dynamic inverse()/determinant() do),
+//                              out[j] = {Sinv00, Sinv10, Sinv01, Sinv11, log det, zp_r, zp_b, 0}
+//   ekf_assoc_scan_kernel    : one wave per observation walks the features IN ORDER, 64 at a time, and reproduces the
+//                              sequential gate logic exactly: a feature sets a new best iff it is inside gate1 and its
+//                              nd is below every earlier gated nd (exclusive prefix minimum); every other feature
+//                              feeds `outer` with its nis (EKF.cpp:280-283: the else-branch also sees gated
+//                              features that did not set a record).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_assoc_feature_kernel(const T* __restrict__ X, const T* __restrict__ P, int ldp,
+                                                                 int n, T r00, T r10, T r01, T r11, int lower,
+                                                                 T* __restrict__ out)
+{
+    const int nf = (n - 3) / 2;
+    const int j  = blockIdx.x * 256 + threadIdx.x; // 0-based feature
+    if (j >= nf)
+    {
+        return;
+    }
+    T   coef[10], v[2];
+    int fx;
+    // observe_model with z = 0: v = -zp (range), pi2pi(-bearing): recompute zp directly instead
+    observe_model<T>(X, n, j + 1, (T)0, (T)0, coef, v, &fx);
+    const T dx = X[fx] - X[0], dy = X[fx + 1] - X[1];
+    const T zr = dsqrt(dx * dx + dy * dy);
+    const T zb = datan2(dy, dx) - X[2];
+    const int idx[5] = {0, 1, 2, fx, fx + 1};
+    // HP[r][c] for the five columns c that H touches
+    T HP[2][5];
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+    {
+        T p[5];
+#pragma unroll
+        for (int l = 0; l < 5; l++)
+        {
+            p[l] = p_sym<T>(P, ldp, idx[l], idx[c], lower);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+            T sm = coef[5 * r + 0] * p[0];
+            sm += coef[5 * r + 1] * p[1];
+            sm += coef[5 * r + 2] * p[2];
+            sm += coef[5 * r + 3] * p[3];
+            sm += coef[5 * r + 4] * p[4];
+            HP[r][c] = sm;
+        }
+    }
+    T S[2][2]; // S[r][c]
+    const T R[2][2] = {{r00, r01}, {r10, r11}};
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+    {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+            T sm = HP[r][0] * coef[5 * c + 0];
+            sm += HP[r][1] * coef[5 * c + 1];
+            sm += HP[r][2] * coef[5 * c + 2];
+            sm += HP[r][3] * coef[5 * c + 3];
+            sm += HP[r][4] * coef[5 * c + 4];
+            S[r][c] = sm + R[r][c];
+        }
+    }
+    // partially pivoted LU of [[a b],[c d]]
+    const T a = S[0][0], b = S[0][1], c2 = S[1][0], d = S[1][1];
+    const bool sw = dabs(c2) > dabs(a);
+    const T u00 = sw ? c2 : a, u01 = sw ? d : b;
+    const T l10 = (sw ? a : c2) / u00;
+    const T u11 = (sw ? b : d) - l10 * u01;
+    const T det = sw ? -(u00 * u11) : (u00 * u11);
+    // inverse, column by column: x = e_perm, forward (unit lower), backward (upper)
+    T inv[2][2]; // inv[r][c]
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+    {
+        T x0 = ((sw ? 1 : 0) == c) ? (T)1 : (T)0; // perm[0] == c
+        T x1 = ((sw ? 0 : 1) == c) ? (T)1 : (T)0; // perm[1] == c
+        x1 -= l10 * x0;
+        x1        = x1 / u11;
+        x0        = (x0 - u01 * x1) / u00;
+        inv[0][c] = x0;
+        inv[1][c] = x1;
+    }
+    T* o = out + (size_t)j * 8;
+    o[0] = inv[0][0];
+    o[1] = inv[1][0];
+    o[2] = inv[0][1];
+    o[3] = inv[1][1];
+    o[4] = dlog(det);
+    o[5] = zr;
+    o[6] = zb;
+    o[7] = (T)0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) ekf_assoc_scan_kernel(const T* __restrict__ feat, int nf, const T* __restrict__ Z,
+                                                             int m, T gate1, T gate2, int* __restrict__ idf_out,
+                                                             int* __restrict__ kind)
+{
+    const int i    = blockIdx.x;
+    const int lane = threadIdx.x;
+    const T   z0 = Z[2 * i], z1 = Z[2 * i + 1];
+    const T   inf = (T)INFINITY;
+    T         nbest = inf, outer = inf;
+    int       jbest = 0;
+    for (int base = 0; base < nf; base += 64)
+    {
+        const int  j     = base + lane;
+        const bool valid = j < nf;
+        const T*   f     = feat + (size_t)(valid ? j : 0) * 8;
+        const T    v0    = z0 - f[5];
+        const T    v1    = pi2pi<T>(z1 - f[6]);
+        const T    t0    = v0 * f[0] + v1 * f[1]; // (V^T Sinv)[0] = v0*Sinv00 + v1*Sinv10
+        const T    t1    = v0 * f[2] + v1 * f[3];
+        const T    nis   = t0 * v0 + t1 * v1;
+        const T    nd    = nis + f[4];
+        const bool gated = valid && (nis < gate1);
+        const T    cand  = (gated && nd == nd) ? nd : inf;
+        // inclusive prefix minimum over the wave, then shift by one lane
+        T incl = cand;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1)
+        {
+            const T up = __shfl_up(incl, dlt);
+            if (lane >= dlt)
+            {
+                incl = (up < incl) ? up : incl;
+            }
+        }
+        T excl = __shfl_up(incl, 1);
+        excl   = (lane == 0) ? inf : excl;
+        const T    before = (nbest < excl) ? nbest : excl;
+        const bool record = gated && (nd < before);
+        if (valid && !record && nis < outer)
+        {
+            outer = nis;
+        }
+        const T cmin = __shfl(incl, 63);
+        if (cmin < nbest)
+        {
+            const unsigned long long hits = __ballot(cand == cmin);
+            jbest                         = base + __builtin_ctzll(hits) + 1;
+            nbest                         = cmin;
+        }
+    }
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1)
+    {
+        const T o = __shfl_xor(outer, dlt);
+        outer     = (o < outer) ? o : outer;
+    }
+    if (lane == 0)
+    {
+        idf_out[i] = jbest;
+        kind[i]    = (jbest != 0) ? 1 : ((outer > gate2) ? 2 : 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Deferred downdates.  The engine may hold the covariance as  P = Ps - Wp*Wp^T  with Ps the matrix stored
 // in HBM ("stale") and Wp (n x kp) the W1 panels of updates whose P-GEMM has not been applied yet; one
 // P-GEMM with k = kp then applies them all (slam.h:260 is linear in the panels).  Every reader of P adds the

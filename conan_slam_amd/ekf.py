@@ -156,8 +156,35 @@ class EKF:
         """Slam::observeHeading(X, P, phi, useHeading) -- EKF.cpp:328-352 (default false, slam.h:788)."""
         check(self._L.cslam_ekf_observe_heading(self._h, C.c_double(float(phi)), C.c_int(1 if use_heading else 0)))
 
+    def associate(self, Z, R, gate1, gate2):
+        """Raw result of the gated nearest-neighbour search (EKF.cpp:235-326 with computeAssociation EKF.cpp:131-144):
+        (idf[m], kind[m]); kind 1 = associated with the 1-based feature idf[i], 2 = new feature, 0 = dropped."""
+        Z = np.asarray(Z, dtype=self.dtype, order="F").reshape(2, -1, order="F")
+        R = np.asarray(R, dtype=self.dtype, order="F")
+        m = Z.shape[1]
+        idf = np.zeros(max(m, 1), dtype=np.int32)
+        kind = np.zeros(max(m, 1), dtype=np.int32)
+        check(self._L.cslam_ekf_associate(self._h, Z.ctypes.data_as(C.c_void_p), C.c_int(m), R.ctypes.data_as(C.c_void_p),
+                                          C.c_double(float(gate1)), C.c_double(float(gate2)),
+                                          idf.ctypes.data_as(C.POINTER(C.c_int)), kind.ctypes.data_as(C.POINTER(C.c_int))))
+        return idf[:m], kind[:m]
+
+    def data_associate(self, Z, R, gate1, gate2):
+        """Slam::dataAssociate(X, P, Z, R, gate1, gate2) -> (ZF, ZN, idf) -- EKF.cpp:235-326.
+        Under REF_EXACT quirks ZN is EMPTY, as in the reference (EKF.cpp:307 re-declares ZN inside the try block, so the
+        returned matrix is the 0 x 0 one of line 243); TEXTBOOK returns the new-feature observations the loop found."""
+        Z = np.asarray(Z, dtype=self.dtype, order="F").reshape(2, -1, order="F")
+        idf, kind = self.associate(Z, R, gate1, gate2)
+        ZF = np.asfortranarray(Z[:, kind == 1])
+        if self.quirks == Q_REF_EXACT:
+            ZN = np.zeros((0, 0), dtype=self.dtype)
+        else:
+            ZN = np.asfortranarray(Z[:, kind == 2])
+        return ZF, ZN, idf[kind == 1].astype(np.int32)
+
     # reference-style aliases
     observeHeading = observe_heading
+    dataAssociate = data_associate
 
     # ------------------------------------------------------------------ measurement / introspection
     def set_profiling(self, mode: int):

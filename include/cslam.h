@@ -114,6 +114,17 @@ int cslam_ekf_augment(cslam_ekf_t h, const void* Z, int q, const void* R);
  * josephUpdate slam.h:700-725 (evaluated in its exact rank-structured O(n^2) form). */
 int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading);
 
+/* Gated nearest-neighbour data association: Slam::dataAssociate (slam.h, implemented at EKF.cpp:235-326 with
+ * EKF::computeAssociation EKF.cpp:131-144).  Z: 2 x m observations (host pointer, column-major), R: 2 x 2.
+ * For observation i: kind_out[i] = 1 and idf_out[i] = the 1-based feature with the smallest normalised distance
+ * among those whose normalised innovation squared is below gate1; otherwise idf_out[i] = 0 and kind_out[i] = 2 when
+ * the best NIS of the remaining features exceeds gate2 (far enough to be a new feature) or 0 (ambiguous: dropped).
+ * The reference's own return value carries an EMPTY new-feature list (EKF.cpp:307 re-declares ZN, :311 never
+ * advances the column): a REF_EXACT caller ignores kind == 2, see conan_slam_amd/ekf.py::data_associate.
+ * Synchronous (results are written to host memory). Pending deferred downdates are applied first. */
+int cslam_ekf_associate(cslam_ekf_t h, const void* Z, int m, const void* R, double gate1, double gate2, int* idf_out,
+                        int* kind_out);
+
 /* Deferred downdates.  slam.h:260 (P = P - W1*W1^T) is linear in the W1 panels, so the engine may keep
  * P = Ps - Wp*Wp^T with up to max_pending_columns columns of not-yet-applied panels and apply them in ONE
  * P-GEMM (k = pending columns): every reader of P adds the rank-k correction for the columns it touches, so

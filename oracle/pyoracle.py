@@ -173,6 +173,30 @@ class Oracle:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, self.ct, C.c_int]
         f(_ptr(X), _ptr(P), n, P.shape[0], float(phi), 1 if use else 0)
 
+    def compute_association(self, X, P, n, z, R, idf):
+        """EKF.cpp:131-144 -> (nis, nd)"""
+        self._chk(X), self._chk(P)
+        z, R = self.arr(z), self.arr(R, order="F")
+        out = np.zeros(2, dtype=self.dtype)
+        f = self._f("orc_ekf_compute_association")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        f(_ptr(X), _ptr(P), n, P.shape[0], _ptr(z), _ptr(R), int(idf), _ptr(out))
+        return out[0], out[1]
+
+    def data_associate(self, X, P, n, Z, R, gate1, gate2):
+        """EKF.cpp:235-326 -> (idf[m] 1-based or 0, kind[m]: 0 dropped / 1 associated / 2 new feature)"""
+        self._chk(X), self._chk(P)
+        Z = self.arr(Z, order="F")
+        R = self.arr(R, order="F")
+        m = Z.shape[1] if Z.ndim == 2 else Z.size // 2
+        idf = np.zeros(m, dtype=np.int32)
+        kind = np.zeros(m, dtype=np.int32)
+        f = self._f("orc_ekf_data_associate")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, self.ct, self.ct,
+                      C.c_void_p, C.c_void_p]
+        f(_ptr(X), _ptr(P), n, P.shape[0], _ptr(Z), m, _ptr(R), float(gate1), float(gate2), _ptr(idf), _ptr(kind))
+        return idf, kind
+
     # ---- simulator helpers
     def vehicle_model(self, Xv, v, swa, wb, dt):
         self._chk(Xv)

@@ -23,6 +23,7 @@
 #define M_FMOD fmodf
 #define M_FABS fabsf
 #define M_EXP expf
+#define M_LOG logf
 #include "slam_oracle_impl.inc"
 #include "slam_oracle_pf.inc"
 #undef T
@@ -34,6 +35,7 @@
 #undef M_FMOD
 #undef M_FABS
 #undef M_EXP
+#undef M_LOG
 
 /* ------------------------------------------------ double */
 #define T double
@@ -45,6 +47,7 @@
 #define M_FMOD fmod
 #define M_FABS fabs
 #define M_EXP exp
+#define M_LOG log
 #include "slam_oracle_impl.inc"
 #include "slam_oracle_pf.inc"
 #undef T
@@ -56,6 +59,7 @@
 #undef M_FMOD
 #undef M_FABS
 #undef M_EXP
+#undef M_LOG
 
 /* ---------------------------------------------------------------- EKF.cpp:146-233 */
 int orc_data_associate_table(const void* Z, const int* tags, int m, int* table, int nf, void* ZF, int* idf,

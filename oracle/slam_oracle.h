@@ -59,6 +59,17 @@ extern "C" {
     void orc_joseph_update_##S(T* X, T* P, int n, int ldp, const T* V, const T* R, const T* H, int k);      \
     /* EKF.cpp:354-404: Zp (2), H (2 x n, ld 2, zero-filled) */                                             \
     void orc_ekf_observe_model_##S(const T* X, int n, int idf, T* Zp, T* H);                                \
+    /* EKF.cpp:131-144: normalised innovation squared and normalised distance of observation z against    \
+       feature idf (1-based), dense operation order; out[0] = nis, out[1] = nd */                          \
+    void orc_ekf_compute_association_##S(const T* X, const T* P, int n, int ldp, const T* z, const T* R,    \
+                                         int idf, T* out);                                                  \
+    /* EKF.cpp:235-326: gated nearest neighbour, linear search.  kind[i]: 0 dropped, 1 associated with     \
+       feature idf_out[i] (1-based), 2 far enough from everything (outer > gate2) to be a new feature.     \
+       (The reference's return statement hands back an EMPTY new-feature list because line 307 re-declares \
+       ZN inside the try block and line 311 never advances its column index; kind = 2 is what the loop     \
+       decided, the caller applies that quirk.) */                                                         \
+    void orc_ekf_data_associate_##S(const T* X, const T* P, int n, int ldp, const T* Z, int m, const T* R,  \
+                                    T gate1, T gate2, int* idf_out, int* kind);                             \
     /* EKF.cpp:406-455 */                                                                                   \
     void orc_ekf_predict_##S(T* X, T* P, int n, int ldp, T v, T swa, const T* Q, T wb, T dt, int quirks);   \
     /* EKF.cpp:93-129 */                                                                                    \

@@ -462,3 +462,73 @@ def test_full_size_5000_landmarks_one_update(gpu_required):
     assert np.array_equal(Pg, Pg.T), "the update must keep P exactly symmetric"
     assert eng.trace() < tr0
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N", [0, 1, 5, 70, 300])
+def test_data_association_matches_the_oracle(gpu_required, dtype, N):
+    """cslam_ekf_associate (EKF.cpp:131-144, 235-326) against the oracle's sequential loop: same feature, same
+    decision for every observation (integer outputs: exact), over true features, far points and ambiguous ones."""
+    from pyoracle import Oracle
+
+    X, P = make_scenario(N, dtype, seed=40 + N, corr=0.2)
+    eng = _engine(N, dtype, REF_EXACT, X, P, extra=1)
+    o = Oracle(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    rng = np.random.default_rng(N)
+    cols = []
+    if N > 0:
+        ids = (rng.permutation(N)[: min(N, 9)] + 1).astype(np.int32)
+        cols.append(make_obs(X, ids, dtype, seed=N + 1))                       # near true features
+        cols.append(make_obs(X, ids[:3], dtype, seed=N + 2, sr=3.0, sb=0.2))   # noisy: some leave the gate
+    far = np.array([[2500.0, 4000.0], [0.3, -2.0]], dtype=dtype)
+    cols.append(np.asfortranarray(far))
+    Z = np.asfortranarray(np.concatenate(cols, axis=1))
+    for gate1, gate2 in ((4.0, 25.0), (9.0, 16.0)):
+        idf, kind = eng.associate(Z, R, gate1, gate2)
+        idf_o, kind_o = o.data_associate(X, P, X.size, Z, R, gate1, gate2)
+        assert np.array_equal(kind, kind_o), (kind, kind_o)
+        assert np.array_equal(idf, idf_o), (idf, idf_o)
+    # reference-shaped wrapper: REF_EXACT returns the reference's empty ZN, TEXTBOOK the observations the loop found
+    ZF, ZN, idff = eng.data_associate(Z, R, 4.0, 25.0)
+    idf1, kind1 = o.data_associate(X, P, X.size, Z, R, 4.0, 25.0)
+    assert ZF.shape == (2, int((kind1 == 1).sum())) and ZN.shape == (0, 0)
+    assert np.array_equal(idff, idf1[kind1 == 1])
+    eng.close()
+    from conan_slam_amd import EKF
+
+    tb = EKF(N + 1, dtype=dtype, quirks=TEXTBOOK)
+    tb.set_state(X, P)
+    _, ZN2, _ = tb.data_associate(Z, R, 4.0, 25.0)
+    assert ZN2.shape == (2, int((kind1 == 2).sum()))
+    tb.close()
+
+
+def test_data_association_at_full_size_and_under_pending_downdates(gpu_required):
+    """N = 5000 (BASELINE configs[2] size): observations of known features come back with their own index; the
+    answer does not depend on whether covariance downdates are pending (deferred mode flushes first)."""
+    from conan_slam_amd import EKF
+    from conan_slam_amd.synth import Workload
+
+    w = Workload(5000, 32, np.float32)
+    a = EKF(5000, dtype=np.float32, quirks=TEXTBOOK)
+    a.set_state(w.X0, w.P0)
+    b = EKF(5000, dtype=np.float32, quirks=TEXTBOOK)
+    b.set_state(w.X0, w.P0)
+    b.set_deferred(128)
+    for t in range(2):
+        v, swa = w.controls(t)
+        Z, idf = w.observations(t)
+        for e in (a, b):
+            e.predict(v, swa, w.QE, w.wb, w.dt)
+            e.update(Z, w.RE, idf, batch=True)
+    Z, idf = w.observations(2)
+    ia, ka = a.associate(Z, w.RE, 9.0, 25.0)
+    ib, kb = b.associate(Z, w.RE, 9.0, 25.0)
+    assert np.array_equal(ia, ib) and np.array_equal(ka, kb)
+    hit = ka == 1
+    # (a 5000-landmark random map has near-coincident landmarks: a few observations are closer, in the normalised
+    # distance, to a neighbour than to the feature they were generated from)
+    assert hit.sum() >= 0.8 * len(idf) and (ia[hit] == np.asarray(idf)[hit]).mean() >= 0.8
+    a.close()
+    b.close()
