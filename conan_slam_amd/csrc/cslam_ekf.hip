@@ -889,6 +889,12 @@ struct Ekf : EkfBase
                 return eigen_fallback(k, deferring);
             }
         }
+        // deferred mode: once the pending store is full, apply it now rather than at the start of the next update --
+        // the predict in between then has no pending panels to transform
+        if (!keep_pending && defer_max > 0 && kp >= defer_max && (rc = flush()))
+        {
+            return rc;
+        }
         return CSLAM_OK;
     }
 

@@ -1449,6 +1449,18 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
     f32x16     acc  = {0};
     float      xs   = 0.f;
     const float* pa = A + row0 + lj;
+    // SUB: the old values of the output tile are requested first, so that their latency (the tile was written by
+    // another kernel on other XCDs a moment ago) hides behind the operand loads and the MFMAs
+    float oldv[16];
+    if (SUB)
+    {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int col = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            oldv[r]       = OUT[(size_t)(col < nc ? col : nc - 1) * ldo + row0 + lj];
+        }
+    }
     constexpr int NP = 32; // k-pairs per trip: every load of the trip is issued before its first MFMA
     for (int qb = 0; qb < kq; qb += 2 * NP)
     {
@@ -1480,7 +1492,7 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
         if (col < nc)
         {
             float* o = OUT + (size_t)col * ldo + row0 + lj;
-            *o       = SUB ? (*o - acc[r]) : acc[r];
+            *o       = SUB ? (oldv[r] - acc[r]) : acc[r];
         }
     }
     if (dox)
