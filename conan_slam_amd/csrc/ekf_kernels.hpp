@@ -94,7 +94,7 @@ __device__ inline void observe_model(const T* __restrict__ X, int n, int idf, T 
 // (EKF.cpp:394-395), which in column-major P are contiguous columns -> fully coalesced reads.
 // grid = (ceil(n/256), ceil(m/kGatherObs)), block = 256.
 // ------------------------------------------------------------------------------------------------
-constexpr int kGatherObs = 8;
+constexpr int kGatherObs = 1; // measured at N = 5000, m = 32: 11.1 us (8 per block), 10.2 (4), 9.5 (2), 8.7 (1): the kernel is a latency chain, more blocks win
 
 template <typename T>
 __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X, const T* __restrict__ P, int ldp,
