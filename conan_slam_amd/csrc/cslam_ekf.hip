@@ -37,6 +37,7 @@ struct EkfBase
     int         ldp      = 0; // padded leading dimension / column count
     int         n        = 3;
     int         sync_mode = 1;
+    int         tune_gain = 0; // env CSLAM_TUNE_GAIN: 0 explicit inverse in the factor kernel + MFMA product gain (shipped); 1 triangular-solve gain ekf_gain_solve_f32 (f32, 16 < k <= 64): measured factor 23.5 -> 18.7 us but gain 7.7 -> 18.3 us at N = 5000, k = 64
     int         tune_downdate = 0; // env CSLAM_TUNE_DOWNDATE: 0 shipped (persistent symmetric; k<=64: memory ops inside the MFMA loop), 1 tile-per-workgroup full, 2 persistent symmetric unpipelined, 3 pipelined across tiles only, 4 first version
     int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
     int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (readlane one-wave up to k=64, workgroup-parallel up to 128 in f32, general beyond), 2 general always, 3 workgroup-parallel always, 5 blocked 2x2 (f32, 32<k<=64)
@@ -78,6 +79,10 @@ struct Ekf : EkfBase
     T*   dS    = nullptr;
     T*   dG    = nullptr;
     T*   dSub  = nullptr; // (3 + 64) x 64 compact block of PHT (see ekf_gather_kernel)
+    T*   dL    = nullptr; // solve mode: the factor L (64 x 64) and 1/diag(L) (64) of the last update
+    T*   dRdiag = nullptr;
+    bool solve_gain = false; // the last factor launch published L instead of G (ekf_gain_solve_f32 follows)
+    int  solve_K    = 0;
     bool sub_valid = false;
     T*   dGt   = nullptr;
     T*   dV    = nullptr;
@@ -175,13 +180,15 @@ struct Ekf : EkfBase
         (void)hipFree(dS);
         (void)hipFree(dG);
         (void)hipFree(dSub);
+        (void)hipFree(dL);
+        (void)hipFree(dRdiag);
         (void)hipFree(dGt);
         (void)hipFree(dV);
         (void)hipFree(dt_);
         (void)hipFree(dU);
         (void)hipFree(dScrS);
         (void)hipFree(dScrG);
-        dPHT = dS = dG = dSub = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
+        dPHT = dS = dG = dSub = dL = dRdiag = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
     }
 
     int use_device() { CSLAM_HIP_TRY(hipSetDevice(device)); return CSLAM_OK; }
@@ -290,6 +297,8 @@ struct Ekf : EkfBase
         if (dSub == nullptr)
         {
             CSLAM_HIP_TRY(hipMalloc(&dSub, (size_t)(3 + 64) * 64 * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dL, (size_t)64 * 64 * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dRdiag, (size_t)64 * sizeof(T)));
         }
         CSLAM_HIP_TRY(hipMalloc(&dGt, kk));
         CSLAM_HIP_TRY(hipMalloc(&dScrS, kk));
@@ -692,6 +701,9 @@ struct Ekf : EkfBase
         a.textbook = (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1;
         a.stamps   = dStamps;
         a.sub      = sub_valid ? dSub : nullptr;
+        a.dL       = nullptr;
+        a.dRdiag   = nullptr;
+        solve_gain = false;
         a.lds_S    = 1;
         a.lds_G    = 1;
         {
@@ -747,6 +759,13 @@ struct Ekf : EkfBase
                 // rank-1 updates on the matrix cores (A/B: CSLAM_TUNE_FACTOR=1 selects the readlane kernel)
                 if (k > 16 && tune_factor == 0)
                 {
+                    if (tune_gain == 1) // experiment: the gain kernel applies inv(L) by substitution (publish L, skip the inverse)
+                    {
+                        a.dL       = dL;
+                        a.dRdiag   = dRdiag;
+                        solve_gain = true;
+                        solve_K    = (k <= 32) ? 32 : 64;
+                    }
                     if (k <= 32)
                     {
                         hipLaunchKernelGGL((ekf_factor_mfma_f32<32>), dim3(1), dim3(256), 0, stream, a, dU);
@@ -923,6 +942,7 @@ struct Ekf : EkfBase
         }
         CSLAM_HIP_TRY(hipMemcpyAsync(dG, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         CSLAM_HIP_TRY(hipMemcpyAsync(dGt, Gt.data(), Gt.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        solve_gain = false; // the fallback gain is a general matrix: apply it with the product kernel
         CSLAM_HIP_TRY(hipMemcpyAsync(dt_, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         std::vector<T> u((size_t)k, (T)0);
         for (int q = 0; q < k; q++)
@@ -1162,9 +1182,45 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipMemcpyAsync(S, dS, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
         }
-        if (G)
+        if (G && !solve_gain)
         {
             CSLAM_HIP_TRY(hipMemcpyAsync(G, dG, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
+        }
+        if (G && solve_gain)
+        {
+            // solve mode never forms G on the device: G = inv(L) (REF_EXACT) or inv(L)^T (TEXTBOOK) from the
+            // published factor, by substitution in double precision
+            const int      K = solve_K;
+            std::vector<T> L((size_t)K * K);
+            int            fl[2] = {0, 0};
+            CSLAM_HIP_TRY(hipMemcpyAsync(L.data(), dL, L.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipMemcpyAsync(fl, dFlags, sizeof(fl), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            std::vector<double> X((size_t)k * k, 0.0); // inv(L), column-major k x k
+            if (fl[1] == 0)
+            {
+                for (int c = 0; c < k; c++)
+                {
+                    for (int r = c; r < k; r++)
+                    {
+                        double sacc = (r == c) ? 1.0 : 0.0;
+                        for (int q = c; q < r; q++)
+                        {
+                            sacc -= (double)L[(size_t)q * K + r] * X[(size_t)c * k + q];
+                        }
+                        X[(size_t)c * k + r] = sacc / (double)L[(size_t)r * K + r];
+                    }
+                }
+            }
+            const bool tb  = !(quirks & CSLAM_Q_LOWER_CHOL_GAIN);
+            T*         out = static_cast<T*>(G);
+            for (int c = 0; c < k; c++)
+            {
+                for (int r = 0; r < k; r++)
+                {
+                    out[(size_t)c * k + r] = (T)(tb ? X[(size_t)r * k + c] : X[(size_t)c * k + r]);
+                }
+            }
         }
         if (V)
         {
@@ -1334,6 +1390,25 @@ int Ekf<float>::launch_downdate(const float* W, int k)
 template <>
 bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot)
 {
+    if (solve_gain) // the factor kernel published L: W1 by substitution, X += W1 * t fused
+    {
+        const bool tb   = !(quirks & CSLAM_Q_LOWER_CHOL_GAIN);
+        const int  k8   = round_up(k, 8);
+        const dim3 grid((n_pad + 255) / 256), block(256);
+#define CSLAM_LAUNCH_SOLVE(KK, TB)                                                                                   \
+    hipLaunchKernelGGL((ekf_gain_solve_f32<KK, TB>), grid, block, 0, stream, dPHT, ldp, n, n_pad, k, k8, dL, dRdiag, dV, \
+                       dFlags, slot, ldp, dX)
+        if (solve_K == 32)
+        {
+            if (tb) { CSLAM_LAUNCH_SOLVE(32, true); } else { CSLAM_LAUNCH_SOLVE(32, false); }
+        }
+        else
+        {
+            if (tb) { CSLAM_LAUNCH_SOLVE(64, true); } else { CSLAM_LAUNCH_SOLVE(64, false); }
+        }
+#undef CSLAM_LAUNCH_SOLVE
+        return true;
+    }
     if (k > 128 || (k > 64 && tune_factor != 0 && tune_factor != 3))
     {
         return false; // du is produced by the tuned factor kernels only
@@ -1484,6 +1559,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* tv = getenv("CSLAM_TUNE_DOWNDATE"))
     {
         b->tune_downdate = atoi(tv);
+    }
+    if (const char* tg = getenv("CSLAM_TUNE_GAIN"))
+    {
+        b->tune_gain = atoi(tg);
     }
     // Block-lower storage: only 128x128 tiles on/below the tile diagonal of the symmetric P are maintained
     // (the P-GEMM then writes each tile once).  Needs the persistent symmetric kernel -> f32 default path only.

@@ -569,6 +569,8 @@ struct FactorArgs
     T*         scratchG;
     long long* stamps; // diagnostic: s_memtime at phase boundaries (nullptr in production)
     const T*   sub;    // compact (3+2m) x 2m block of PHT written by ekf_gather_kernel, or nullptr
+    T*         dL;     // solve mode (ekf_gain_solve_f32): the factor L (K x K) is published instead of G; or nullptr
+    T*         dRdiag; // 1 / diag(L), K values
     int        lds_S; // 1: S in LDS
     int        lds_G; // 1: G in LDS
     int        textbook;

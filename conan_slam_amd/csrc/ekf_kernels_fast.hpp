@@ -602,11 +602,42 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
             }
         }
         stamp(2);
+        T chk = (T)0;
+        if (a.dL != nullptr)
+        {
+            // Solve mode (ekf_gain_solve_f32 applies inv(L) by substitution): publish L and 1/diag, no inverse.
+            // L goes through the LDS area of G: column j, rows from the lanes that hold them.
+#pragma unroll
+            for (int j = 0; j < K; j++)
+            {
+                const bool onh = on_half(j);
+                if (j < 32)
+                {
+                    Gm[onh ? lc + j * LD : trash] = la0[j];
+                    chk                           = __builtin_fmaf(la0[j], (T)0, chk);
+                }
+                if (K == 64)
+                {
+                    Gm[onh ? 32 + lc + j * LD : trash] = la1[j];
+                    chk                                = __builtin_fmaf(la1[j], (T)0, chk);
+                }
+                chk = __builtin_fmaf(rdiag[j], (T)0, chk);
+            }
+            if (lane == 0)
+            {
+#pragma unroll
+                for (int j = 0; j < K; j++)
+                {
+                    tvec[j] = rdiag[j];
+                }
+            }
+        }
+        else
+        {
         // ---- inv(L): R = I, then for every q: X[q][:] = R[q][:] / L[q][q], R -= L[:, q] X[q][:] ----
         // X[q][c] goes to Gm[q + c*LD] (the transposition for TEXTBOOK happens when G is read back); per-lane base
         // addresses, one per half: lanes outside the half point at their scratch slot.  chk turns NaN as soon as
         // one entry of X is not finite (0*Inf = NaN, 0*NaN = NaN): no compare in the loop.
-        T chk = (T)0;
         {
             f32x16 R00, R10, R11;
 #pragma unroll
@@ -659,6 +690,7 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
                 }
             }
         }
+        }
         stamp(3);
         const bool bad = (__ballot(!(chk == chk)) != 0ull);
         if (lane == 0)
@@ -682,6 +714,34 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
             }
         }
         __syncthreads();
+    }
+    if (a.dL != nullptr)
+    {
+        // solve mode: L (K x K, column-major, zeros above the diagonal, identity padding) and 1/diag; zeros if flagged
+        constexpr int NE = (K * K + 255) / 256;
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1), c = e / K;
+            a.dL[e]     = (r >= c) ? Gm[r + c * LD] : (T)0;
+        }
+        if (tid < K)
+        {
+            a.dRdiag[tid] = zero ? (T)0 : tvec[tid];
+        }
+        stamp(9);
+        stamp(4);
+        if (tid == 0)
+        {
+            const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
+            a.flags[1]     = code;
+            if (code)
+            {
+                atomicOr(&a.flags[0], code);
+            }
+        }
+        return;
     }
     // outputs: G, G^T (coalesced), t = G^T V, u = G t.   G[r][c]: REF_EXACT G = inv(L) = X, TEXTBOOK G = X^T
     const int gr = a.textbook ? LD : 1, gc = a.textbook ? 1 : LD;
@@ -1416,6 +1476,173 @@ __global__ void __launch_bounds__((4 * K < 64) ? 64 : 4 * K) ekf_factor_par_kern
         {
             atomicOr(&a.flags[0], code);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 (f32), triangular-solve form for 16 < k <= 64: W1 = PHT * inv(L)^T (TEXTBOOK) or PHT * inv(L) (REF_EXACT,
+// slam.h:257 with the lower factor of slam.h:423) WITHOUT forming inv(L): one lane owns one row p of PHT (K values in
+// registers) and solves  w A = p  for a lower-triangular A by blocks of four columns, last block first.  The
+// multipliers are the same for every row, so they come from LDS as 16-byte broadcast reads (M[c + q*K] = A[q][c]),
+// two v_pk_fma_f32 per read.  REF_EXACT: A = L.  TEXTBOOK: w L^T = p is the same problem with every index reversed
+// (J L^T J is lower triangular), so the one code path serves both with a compile-time index map.
+// The factor kernel then stops after the Cholesky factorisation: the triangular inverse (13 k cycles) and the
+// G / G^T / t / u outputs (8 k) leave the serial chain; substitution is also the better conditioned way to apply a
+// triangular inverse.  X += W1 * t fused, t = inv(A)^T V' solved per wave from the factor in LDS (slam.h:258-259
+// regrouped: W V = W1 (inv(L) V) resp. W1 (inv(L)^T V)).  flags[1] != 0 (LLT failure / non-finite factor): W1 = 0,
+// X kept.  grid = ceil(n_pad / 256) workgroups of 4 waves (64 rows each); writes W1 columns [0, k8).
+// STATUS: correct (parity-green in both quirk modes) but NOT the shipped path: at N = 5000, k = 64 it takes 18 us
+// against 7.7 us for the MFMA product with the explicit inverse, which outweighs the 5 us the factor kernel saves.
+// Selected with CSLAM_TUNE_GAIN=1.
+// ------------------------------------------------------------------------------------------------
+template <int K, bool TEXTBOOK>
+__global__ void __launch_bounds__(256) ekf_gain_solve_f32(const float* __restrict__ PHT, int ldw, int n, int n_pad, int k,
+                                                          int k8, const float* __restrict__ Lg,
+                                                          const float* __restrict__ rdg, const float* __restrict__ V,
+                                                          const int* __restrict__ flags, float* __restrict__ W1, int ldo,
+                                                          float* __restrict__ X)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float M[K * K]; // M[c + q*K] = A[q][c]
+    __shared__ float rd[K];
+    __shared__ __attribute__((aligned(16))) float ts[4][K];
+    auto ix = [](int c) { return TEXTBOOK ? (K - 1 - c) : c; }; // solve index -> column of L / PHT / W1
+    const int  tid  = threadIdx.x;
+    const int  wave = tid >> 6;
+    const int  lane = tid & 63;
+    const int  row0 = blockIdx.x * 256 + tid;
+    const bool live = row0 < n_pad; // (the last workgroup may reach past the padded row count)
+    const int  row  = live ? row0 : 0;
+    const bool dead = flags[1] != 0;
+    // L (K x K, column-major, identity padding): REF_EXACT A[q][c] = L[q][c]; TEXTBOOK A[q][c] = L[K-1-c][K-1-q]
+    // (all loads of a thread first, then the LDS stores: one L2 round trip instead of sixteen)
+    {
+        constexpr int NE = K * K / 256;
+        float         lv[NE];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            lv[it] = Lg[tid + it * 256];
+        }
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1), c = e / K; // Lg[e] = L[r][c]
+            if (TEXTBOOK)
+            {
+                M[(K - 1 - r) + (K - 1 - c) * K] = lv[it];
+            }
+            else
+            {
+                M[c + r * K] = lv[it];
+            }
+        }
+    }
+    if (tid < K)
+    {
+        rd[ix(tid)] = rdg[tid];
+    }
+    // this lane's row of PHT in solve order (columns >= k are padding: zero)
+    float p[K];
+#pragma unroll
+    for (int c = 0; c < K; c++)
+    {
+        const int  col = ix(c);
+        const float v  = PHT[(size_t)(col < k ? col : 0) * ldw + row];
+        p[c]           = (col < k) ? v : 0.f;
+    }
+    __syncthreads();
+    // ---- t = inv(A)^T v', once per wave: lane c holds element c; column `lane` of A in registers
+    {
+        float acol[K]; // A[q][lane]
+#pragma unroll
+        for (int q = 0; q < K; q++)
+        {
+            acol[q] = (lane < K) ? M[lane + q * K] : 0.f;
+        }
+        const int vi = ix(lane < K ? lane : 0);
+        float     v  = (lane < K && vi < k) ? V[vi] : 0.f;
+#pragma unroll
+        for (int c = K - 1; c >= 0; c--) // A^T t = v: t_c = v_c / A_cc, then v_r -= A[c][r] t_c for r < c
+        {
+            const float tc = bcast(v, c) * rd[c];
+            v              = (lane == c) ? tc : ((lane < c) ? __builtin_fmaf(-acol[c], tc, v) : v);
+        }
+        if (lane < K)
+        {
+            ts[wave][lane] = v;
+        }
+    }
+    // ---- w A = p, four columns at a time, last block first
+#pragma unroll
+    for (int b = K / 4 - 1; b >= 0; b--)
+    {
+        int mo = 0;
+        asm volatile("" : "+v"(mo)); // opaque (zero) offset per block: keeps the optimiser from hoisting every broadcast
+                                     // read of the solve to the top (an opaque POINTER would lose the LDS address space)
+        const float* Mb = M + mo;
+        f32x2 a01 = {p[4 * b], p[4 * b + 1]}, a23 = {p[4 * b + 2], p[4 * b + 3]};
+        // finished columns q > block: A[q][4b..4b+3] = M[4b.. + q*K]; the broadcast reads go out twelve at a time
+        // (left alone, the compiler waits for each one before its two FMAs: 500 exposed LDS round trips)
+        constexpr int QB = 12;
+#pragma unroll
+        for (int q0 = K - 1; q0 >= 4 * b + 4; q0 -= QB)
+        {
+            float4 l[QB];
+#pragma unroll
+            for (int j = 0; j < QB; j++)
+            {
+                const int q = q0 - j;
+                if (q >= 4 * b + 4)
+                {
+                    l[j] = *reinterpret_cast<const float4*>(&Mb[4 * b + q * K]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < QB; j++)
+            {
+                const int q = q0 - j;
+                if (q >= 4 * b + 4)
+                {
+                    const f32x2 wq = {p[q], p[q]};
+                    a01 -= wq * f32x2{l[j].x, l[j].y};
+                    a23 -= wq * f32x2{l[j].z, l[j].w};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the 4 x 4 diagonal block, backward: rows 4b+1..4b+3 of A restricted to the block
+        const float4 r3 = *reinterpret_cast<const float4*>(&Mb[4 * b + (4 * b + 3) * K]); // A[4b+3][4b..4b+3]
+        const float4 r2 = *reinterpret_cast<const float4*>(&Mb[4 * b + (4 * b + 2) * K]);
+        const float4 r1 = *reinterpret_cast<const float4*>(&Mb[4 * b + (4 * b + 1) * K]);
+        const float  w3 = a23[1] * rd[4 * b + 3];
+        const float  w2 = (a23[0] - r3.z * w3) * rd[4 * b + 2];
+        const float  w1 = (a01[1] - r3.y * w3 - r2.y * w2) * rd[4 * b + 1];
+        const float  w0 = (a01[0] - r3.x * w3 - r2.x * w2 - r1.x * w1) * rd[4 * b];
+        p[4 * b]        = w0;
+        p[4 * b + 1]    = w1;
+        p[4 * b + 2]    = w2;
+        p[4 * b + 3]    = w3;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- outputs
+    float xs = 0.f;
+#pragma unroll
+    for (int c = 0; c < K; c++)
+    {
+        const int   col = ix(c);
+        const float w   = dead ? 0.f : p[c];
+        if (col < k8 && live)
+        {
+            W1[(size_t)col * ldo + row] = (col < k) ? w : 0.f;
+        }
+        xs = __builtin_fmaf(w, ts[wave][c], xs);
+    }
+    if (live && row < n && !dead)
+    {
+        X[row] += xs;
     }
 }
 
