@@ -332,10 +332,11 @@ def main():
                          tune_dd not in ("0", "2", "3")) else "lower"
     if args.dtype != "f32" or tune_dd in ("1", "4"):
         kernel_name = "ekf_downdate_" + args.dtype
-    elif k_launch > 64 or tune_dd == "2":
+    elif tune_dd == "2" or k_launch > 128 or (k_launch > 64 and storage != "lower"):
         kernel_name = "ekf_downdate_psym_f32<64,true,%s>" % ("false" if storage == "lower" else "true")
     elif storage == "lower" and tune_dd == "0":
-        kernel_name = "ekf_downdate_psym4_f32<0>"   # memory operations inside the MFMA loop (the shipped path)
+        # memory operations inside the MFMA loop (the shipped path): two chunks of 32 for k <= 64, four for k <= 128
+        kernel_name = "ekf_downdate_psym4_f32<0,%d>" % (2 if k_launch <= 64 else 4)
     else:
         kernel_name = "ekf_downdate_psym3_f32<%s>" % ("false,false" if storage == "lower" else "true,true")
     traffic = None  # physical HBM bytes per launch: from the committed rocprofv3 --pmc summary of this exact configuration
