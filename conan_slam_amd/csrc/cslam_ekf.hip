@@ -1296,6 +1296,9 @@ int Ekf<float>::launch_downdate(const float* W, int k)
                 if (ntmode == 1) { CSLAM_LAUNCH_PSYM4(1, 2); }
                 else if (ntmode == 2) { CSLAM_LAUNCH_PSYM4(2, 2); }
                 else if (ntmode == 3) { CSLAM_LAUNCH_PSYM4(3, 2); }
+                else if (ntmode == 4) { CSLAM_LAUNCH_PSYM4(4, 2); }
+                else if (ntmode == 5) { CSLAM_LAUNCH_PSYM4(5, 2); }
+                else if (ntmode == 6) { CSLAM_LAUNCH_PSYM4(6, 2); }
                 else { CSLAM_LAUNCH_PSYM4(0, 2); }
             }
             else

@@ -2312,7 +2312,8 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
 // Tile hand-out by atomic ticket (see psym3); a ticket requested at the top of tile i is collected at the top of
 // tile i+1, its tile looked up, published through LDS at the top of chunk 1 of tile i+1 and consumed there.
 // ------------------------------------------------------------------------------------------------
-// NTMODE: 0 ordinary accesses, 1 non-temporal loads and stores, 2 loads only, 3 stores only
+// NTMODE: 0 ordinary accesses, 1 non-temporal loads and stores, 2 loads only, 3 stores only,
+//         4 agent-scope (sc1) loads, 5 agent-scope loads and stores, 6 sc1 loads + nt stores (cache-policy experiments)
 // NCH: chunks of 32 columns per tile (2: k <= 64; 4: k <= 128, the deferred flushes).  Chunk c uses LDS buffer pair
 // c & 1; the stores go behind chunk 0, the loads behind chunk 0/1 (NCH = 2) or chunks 1 and 2 (NCH = 4).
 template <int NTMODE, int NCH>
@@ -2339,8 +2340,8 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
 
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int kAuxLd = (NTMODE == 1 || NTMODE == 2) ? 2 : 0; // nt
-    constexpr int kAuxSt = (NTMODE == 1 || NTMODE == 3) ? 2 : 0;
+    constexpr int kAuxLd = (NTMODE == 1 || NTMODE == 2) ? 2 : ((NTMODE >= 4) ? 16 : 0); // bit 1: nt, bit 4: sc1
+    constexpr int kAuxSt = (NTMODE == 1 || NTMODE == 3 || NTMODE == 6) ? 2 : ((NTMODE == 5) ? 16 : 0);
     // (P must be < 4 GiB: ldp < 32768; the host checks.)
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P, 0, (unsigned)((size_t)ldp * ldp * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW =
