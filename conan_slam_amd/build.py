@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcslam_hip.so")
 
-SOURCES = ["cslam_ekf.hip", "cslam_pf.hip"]
+SOURCES = ["cslam_ekf.hip", "cslam_pf.hip", "cslam_sim.hip"]
 HEADERS = ["cslam_common.hpp", "ekf_kernels.hpp", "pf_kernels.hpp", "host_linalg.hpp", "device_math.hpp", "../../include/cslam.h"]
 ARCH = "gfx950"
 

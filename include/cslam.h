@@ -206,6 +206,32 @@ int cslam_pf_get_particle(cslam_pf_t h, int index, void* w, void* Xv, void* Pv, 
 int cslam_pf_set_particle(cslam_pf_t h, int index, const void* w, const void* Xv, const void* Pv,
                           const void* XF, const void* PF, int nf);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device-side observation generator and known-association table: the per-step host work of
+ * the reference's driver (test/main.cpp:139-165) -- a visibility filter over all landmarks and a table lookup per
+ * observation -- with the map, the table, the scan and its split resident in HBM.
+ *   cslam_sim_get_observations      Slam::getObservations, slam.h:575-683 with computeRangeBearing slam.h:339-368:
+ *                                   landmarks with |dx|,|dy| < rmax, in front of the vehicle and inside the range
+ *                                   circle, ascending tag order; Z (2 x m) and tags (1-based) are copied to the host
+ *                                   pointers when these are not NULL.
+ *   cslam_sim_add_observation_noise slam.h:168-178: Z[r][i] += normals[2i+r] * sqrt(R[r][r]) on the device-resident
+ *                                   scan (the N(0,1) draws are an input, as for the particle filter).
+ *   cslam_sim_associate_table       EKF::dataAssociateTable, EKF.cpp:146-233, on the device-resident scan: known tags
+ *                                   -> (ZF, idf = their state position), unknown tags -> ZN, and the table assigns
+ *                                   them the positions n_features+1, n_features+2, ... in scan order.
+ *   cslam_sim_device_ptrs           the device-resident ZF / idf / ZN / Z / tags, e.g. for cslam_ekf_update_device.
+ * All calls are synchronous with respect to their host outputs. */
+typedef struct cslam_sim* cslam_sim_t;
+int cslam_sim_create(const void* LM, int n_landmarks, int dtype, int device, cslam_sim_t* out);
+int cslam_sim_destroy(cslam_sim_t h);
+int cslam_sim_get_observations(cslam_sim_t h, const void* xv_true, double rmax, void* Z, int* tags, int* m);
+int cslam_sim_add_observation_noise(cslam_sim_t h, const void* R, const void* normals);
+int cslam_sim_associate_table(cslam_sim_t h, int n_features, void* ZF, int* idf, int* mf, void* ZN, int* mn);
+int cslam_sim_device_ptrs(cslam_sim_t h, const void** dZF, const int** dIdf, const void** dZN, const void** dZ,
+                          const int** dTags);
+int cslam_sim_get_table(cslam_sim_t h, int* table);
+int cslam_sim_set_table(cslam_sim_t h, const int* table);
+
 #ifdef __cplusplus
 }
 #endif
