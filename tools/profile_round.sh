@@ -1,3 +1,6 @@
+# Round profile recipe (run on the GPU box through gpurun): three rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, MFMA busy +
+# GRBM clock; separate runs, --kernel-trace only), one --kernel-trace --stats run, then the bench lines kept under profiles/.
+# Outputs land in gpurun_out/; tools/pmc_summary.py condenses the counter CSVs.
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
