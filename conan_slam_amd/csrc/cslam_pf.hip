@@ -45,6 +45,7 @@ struct PfBase
     virtual int pack(const int* idx, int count, void* drec)                                   = 0;
     virtual int unpack(const int* idx, int count, const void* drec)                           = 0;
     virtual int gather_local(const int* keep, double w_new)                                   = 0;
+    virtual int resample_local(const void* select, double n_eff, int status, double* neff, int* did) = 0;
     virtual int get_particle(int i, void* w, void* Xv, void* Pv, void* XF, void* PF)          = 0;
     virtual int set_particle(int i, const void* w, const void* Xv, const void* Pv, const void* XF, const void* PF,
                              int nf)                                                          = 0;
@@ -71,6 +72,11 @@ struct Pf : PfBase
             (void)hipStreamSynchronize(stream);
         }
         (void)hipFree(dW);
+        (void)hipFree(dSel);
+        (void)hipFree(dCum);
+        (void)hipFree(dKeep);
+        (void)hipFree(dEnable);
+        (void)hipFree(dInfo);
         (void)hipFree(dXv);
         (void)hipFree(dPv);
         (void)hipFree(dXF);
@@ -478,6 +484,70 @@ struct Pf : PfBase
         return set_uniform_weight(w_new);
     }
 
+    // PF.cpp:473-500 for a single shard that holds the whole particle set, without leaving the device: plan
+    // (sums, normalise, Neff, decision, keep[]) -> pack(keep) -> unpack(identity) -> w = 1/N, the last three gated by a
+    // device flag.  One D2H of {Neff, flag} at the end, and only if the caller asks for them.
+    T*      dSel  = nullptr;
+    T*      dCum  = nullptr;
+    int*    dKeep = nullptr;
+    int*    dEnable = nullptr;
+    double* dInfo = nullptr;
+    int resample_local(const void* select, double n_eff, int status, double* neff, int* did) override
+    {
+        if (!select)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_resample_local: null select");
+        }
+        if (np > kPfPlanMax)
+        {
+            return fail(CSLAM_ERR_CAPACITY, "pf_resample_local: %d particles (limit %d): use the sharded path", np, kPfPlanMax);
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        if (!dSel)
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dSel, (size_t)np * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dCum, (size_t)np * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dKeep, (size_t)np * sizeof(int)));
+            CSLAM_HIP_TRY(hipMalloc(&dEnable, sizeof(int)));
+            CSLAM_HIP_TRY(hipMalloc(&dInfo, 2 * sizeof(double)));
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(dSel, select, (size_t)np * sizeof(T), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(pf_resample_plan_kernel<T>, dim3(1), dim3(256), 0, stream, dW, np, dSel, n_eff, status, dCum, dKeep,
+                           dInfo, dEnable);
+        CSLAM_HIP_TRY(hipGetLastError());
+        const dim3 ggrid(13 + 6 * store().nf, (np + 255) / 256);
+        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 0>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable);
+        CSLAM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 1>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable);
+        CSLAM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(pf_set_weights_if_kernel<T>, dim3((np + 255) / 256), dim3(256), 0, stream, dW, np,
+                           (T)(1.0 / (double)np), dEnable);
+        CSLAM_HIP_TRY(hipGetLastError());
+        if (neff || did)
+        {
+            double info[2] = {0.0, 0.0};
+            CSLAM_HIP_TRY(hipMemcpyAsync(info, dInfo, sizeof(info), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            if (neff)
+            {
+                *neff = info[0];
+            }
+            if (did)
+            {
+                *did = info[1] != 0.0 ? 1 : 0;
+            }
+        }
+        else
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // `select` is pageable host memory: done with it on return
+        }
+        return CSLAM_OK;
+    }
+
     int get_particle(int i, void* w, void* Xv, void* Pv, void* XF, void* PF) override
     {
         if (i < 0 || i >= np)
@@ -725,6 +795,13 @@ int cslam_pf_unpack(cslam_pf_t h, const int* dst_idx, int count, const void* d_r
 {
     CSLAM_NEED(h);
     return B(h)->unpack(dst_idx, count, d_records);
+}
+
+int cslam_pf_resample_local(cslam_pf_t h, const void* select, double n_effective, int resample_status, double* neff,
+                            int* resampled)
+{
+    CSLAM_NEED(h);
+    return B(h)->resample_local(select, n_effective, resample_status, neff, resampled);
 }
 
 int cslam_pf_gather_local(cslam_pf_t h, const int* keep, double w_new)

@@ -849,14 +849,162 @@ __global__ void __launch_bounds__(256) pf_scale_weights_kernel(T* __restrict__ w
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PF::resampleParticles (PF.cpp:473-500) with stratifiedResample (PF.cpp:546-574) for ONE shard holding the whole
+// particle set, entirely on the device: weight sums (same reduction as pf_weight_sums_kernel), normalisation,
+// Neff, the decision, the running sum of the normalised weights in the particle dtype IN INDEX ORDER (one lane: the
+// same sequence of roundings as the reference's loop), and keep[c] = first i with cum[i] > select[c] (equal to the
+// reference's two-pointer walk because select is increasing).  info[0] = Neff, info[1] = 1 if resampling happens.
+// The kernels that move the particles afterwards take `enable` and return at once when it is 0.
+// One workgroup; np <= kPfPlanMax (the sequential running sum bounds it).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPfPlanMax = 8192;
+
+template <typename T>
+__global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w, int np, const T* __restrict__ select,
+                                                                double n_effective, int resample_status,
+                                                                T* __restrict__ cum, int* __restrict__ keep,
+                                                                double* __restrict__ info, int* __restrict__ enable)
+{
+    __shared__ double s1[256], s2[256];
+    __shared__ int    s_do;
+    double            a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256)
+    {
+        double x = (double)w[i];
+        a += x;
+        b += x * x;
+    }
+    s1[threadIdx.x] = a;
+    s2[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1)
+    {
+        if ((int)threadIdx.x < st)
+        {
+            s1[threadIdx.x] += s1[threadIdx.x + st];
+            s2[threadIdx.x] += s2[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    const double ws = s1[0], ws2r = s2[0];
+    const T      scale = (T)(1.0 / ws); // PF.cpp:482-487
+    for (int i = threadIdx.x; i < np; i += 256)
+    {
+        w[i] = w[i] * scale;
+    }
+    // Neff from the raw sums, as the host path does: 1 / sum (w/ws)^2 = ws^2 / sum w^2  (PF.cpp:549-554)
+    const double neff = (ws2r > 0.0) ? (ws * ws) / ws2r : 0.0;
+    if (threadIdx.x == 0)
+    {
+        const int go = (neff < n_effective && resample_status) ? 1 : 0; // PF.cpp:490
+        s_do         = go;
+        info[0]      = neff;
+        info[1]      = (double)go;
+        *enable      = go;
+    }
+    __syncthreads();
+    if (!s_do)
+    {
+        return;
+    }
+    if (threadIdx.x == 0) // PF.cpp:559-563: cumulative sum, sequential, in the particle dtype
+    {
+        T run = w[0];
+        cum[0] = run;
+        for (int i = 1; i < np; i++)
+        {
+            run    = run + w[i];
+            cum[i] = run;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < np; c += 256) // PF.cpp:565-574
+    {
+        const T sc = select[c];
+        int     lo = 0, hi = np; // first i in [0, np) with cum[i] > sc; none -> the reference leaves keep[c] = 0
+        while (lo < hi)
+        {
+            const int mid = (lo + hi) >> 1;
+            if (sc < cum[mid])
+            {
+                hi = mid;
+            }
+            else
+            {
+                lo = mid + 1;
+            }
+        }
+        keep[c] = (lo < np) ? lo : 0;
+    }
+}
+
+// slot i <- particle keep[i] for every row of the SoA store, through a scratch copy in the same layout: both passes
+// read and write along the particle index (coalesced), whereas the record form (pack/unpack: one block per particle)
+// strides by np between consecutive elements.  grid = (rows, ceil(np/256)); PASS 0: tmp <- gather, PASS 1: store <- tmp.
+template <typename T, int PASS>
+__global__ void __launch_bounds__(256) pf_gather_rows_kernel(PfStore<T> s, const int* __restrict__ keep, T* __restrict__ tmp,
+                                                             const int* __restrict__ enable)
+{
+    if (*enable == 0)
+    {
+        return;
+    }
+    const int e = blockIdx.x;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= s.np)
+    {
+        return;
+    }
+    T* row;
+    if (e == 0)
+    {
+        row = s.w;
+    }
+    else if (e < 4)
+    {
+        row = s.xv + (size_t)(e - 1) * s.np;
+    }
+    else if (e < 13)
+    {
+        row = s.pv + (size_t)(e - 4) * s.np;
+    }
+    else if (e < 13 + 2 * s.nf)
+    {
+        row = s.xf + (size_t)(e - 13) * s.np;
+    }
+    else
+    {
+        row = s.pf + (size_t)(e - 13 - 2 * s.nf) * s.np;
+    }
+    if (PASS == 0)
+    {
+        tmp[(size_t)e * s.np + i] = row[keep[i]];
+    }
+    else
+    {
+        row[i] = tmp[(size_t)e * s.np + i];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pf_set_weights_if_kernel(T* __restrict__ w, int np, T value, const int* __restrict__ enable)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (*enable && i < np)
+    {
+        w[i] = value;
+    }
+}
+
 // Packed record of one particle: [w, xv(3), pv(9), xf(2*nf), pf(4*nf)] -- rec_len = 13 + 6*nf scalars.
 // pack: records[j] <- particle idx[j];  grid.x = count, threads stride over the record.
 template <typename T>
 __global__ void __launch_bounds__(256) pf_pack_kernel(PfStore<T> s, const int* __restrict__ idx, int count,
-                                                       T* __restrict__ rec)
+                                                       T* __restrict__ rec, const int* __restrict__ enable = nullptr)
 {
     const int j = blockIdx.x;
-    if (j >= count)
+    if (j >= count || (enable != nullptr && *enable == 0))
     {
         return;
     }
@@ -892,14 +1040,14 @@ __global__ void __launch_bounds__(256) pf_pack_kernel(PfStore<T> s, const int* _
 
 template <typename T>
 __global__ void __launch_bounds__(256) pf_unpack_kernel(PfStore<T> s, const int* __restrict__ idx, int count,
-                                                         const T* __restrict__ rec)
+                                                         const T* __restrict__ rec, const int* __restrict__ enable = nullptr)
 {
     const int j = blockIdx.x;
-    if (j >= count)
+    if (j >= count || (enable != nullptr && *enable == 0))
     {
         return;
     }
-    const int p   = idx[j];
+    const int p   = (idx != nullptr) ? idx[j] : j; // nullptr: identity (record j -> slot j)
     const int len = 13 + 6 * s.nf;
     const T*  in  = rec + (size_t)j * len;
     for (int e = threadIdx.x; e < len; e += 256)

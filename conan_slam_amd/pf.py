@@ -42,13 +42,13 @@ def stratified_random(n: int, uniforms: np.ndarray, dtype=np.float32) -> np.ndar
     offsets are defect #10 of SURVEY 2.1): select[i] = k/2 + i*k + (u[i]*k - k/2), k = 1/n."""
     t = np.dtype(dtype).type
     k = t(1) / t(n)
-    out = np.empty(n, dtype=dtype)
-    di = k / t(2)
-    for i in range(n):
-        if i > 0:
-            di = t(di + k)
-        out[i] = t(di + (t(uniforms[i]) * k - k / t(2)))
-    return out
+    # di_0 = k/2, di_i = di_(i-1) + k: a running sum in the particle dtype (np.cumsum accumulates sequentially in the
+    # requested dtype, i.e. with the same roundings as the reference's loop); the rest is elementwise in that dtype
+    steps = np.full(n, k, dtype=dtype)
+    steps[0] = k / t(2)
+    di = np.cumsum(steps, dtype=dtype)
+    u = np.asarray(uniforms)[:n].astype(dtype)
+    return (di + (u * k - k / t(2))).astype(dtype)
 
 
 def stratified_keep(w_norm: np.ndarray, select: np.ndarray) -> np.ndarray:
@@ -246,6 +246,20 @@ class ParticleShard:
         assert keep.shape[0] == self.n_local
         check(self._L.cslam_pf_gather_local(self._h, _vp(keep), C.c_double(float(w_new))))
 
+    def resample_local(self, select, n_effective: float, resample_status: bool, want_result: bool = True):
+        """PF::resampleParticles (PF.cpp:473-500) for a shard that holds every particle, entirely on the device.
+        -> (neff, resampled) or None when want_result is False (nothing returns to the host)."""
+        select = np.ascontiguousarray(select, dtype=self.dtype)
+        assert select.shape[0] == self.n_local
+        if not want_result:
+            check(self._L.cslam_pf_resample_local(self._h, _vp(select), C.c_double(float(n_effective)),
+                                                  C.c_int(1 if resample_status else 0), None, None))
+            return None
+        neff, did = C.c_double(0.0), C.c_int(0)
+        check(self._L.cslam_pf_resample_local(self._h, _vp(select), C.c_double(float(n_effective)),
+                                              C.c_int(1 if resample_status else 0), C.byref(neff), C.byref(did)))
+        return float(neff.value), bool(did.value)
+
     def pack_into(self, src_idx: np.ndarray, dptr: int):
         src_idx = np.ascontiguousarray(src_idx, dtype=np.int32)
         check(self._L.cslam_pf_pack(self._h, _vp(src_idx), C.c_int(src_idx.shape[0]), C.c_void_p(dptr)))
@@ -311,6 +325,12 @@ def resample_particles(shard, comm, n_effective: int, resample_status: bool, sel
     `uniforms` (N uniform[0,1) draws that every rank must pass identically).  Returns (neff, resampled)."""
     n_local = shard.n_local
     n = n_local * comm.world
+    if comm.world == 1 and hasattr(shard, "resample_local") and n_local <= 8192 and not getattr(shard, "host_resample", False):
+        # one shard holds everything: sums, normalisation, Neff, decision, keep[] and the moves stay on the device
+        if select is None:
+            assert uniforms is not None, "pass select[] or the uniform draws it is built from"
+            select = stratified_random(n, uniforms, shard.dtype)
+        return shard.resample_local(np.asarray(select, dtype=shard.dtype), n_effective, resample_status)
     s1, s2 = shard.weight_sums()
     ws, ws2 = comm.all_reduce_sum([s1, s2])          # collective 1: two scalars
     shard.scale_weights(1.0 / ws)                     # PF.cpp:482-487

@@ -198,6 +198,13 @@ int cslam_pf_pack(cslam_pf_t h, const int* src_idx, int count, void* d_records);
 /* overwrite local slots dst_idx[0..count) from packed records in device memory */
 int cslam_pf_unpack(cslam_pf_t h, const int* dst_idx, int count, const void* d_records);
 /* purely local resample: slot i <- copy of local particle keep[i] (0-based), all weights = w_new */
+/* PF::resampleParticles (PF.cpp:473-500) with stratifiedResample (PF.cpp:546-574) when ONE handle holds the whole
+ * particle set: weight sums, normalisation, Neff, the decision (Neff < n_effective && resample_status), keep[] and
+ * the particle moves all run on the device; `select` are the N strata positions (PF.cpp:557, host pointer).
+ * neff / resampled may be NULL (then nothing returns to the host). Same results as weight_sums + scale_weights +
+ * host keep[] + gather_local. Limited to 8192 particles (the running sum is sequential, as in the reference). */
+int cslam_pf_resample_local(cslam_pf_t h, const void* select, double n_effective, int resample_status, double* neff,
+                            int* resampled);
 int cslam_pf_gather_local(cslam_pf_t h, const int* keep, double w_new);
 /* download one particle (host buffers; any may be NULL): w (1), Xv (3), Pv (9), XF (2*nf), PF (4*nf) */
 int cslam_pf_get_particle(cslam_pf_t h, int index, void* w, void* Xv, void* Pv, void* XF, void* PF);

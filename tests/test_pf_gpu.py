@@ -211,3 +211,31 @@ def test_pack_unpack_roundtrip(gpu_required):
         gw, gX, gP, gXF, gPF = sh.get_particle(int(d))
         assert gw == parts[s][0] and np.array_equal(gX, parts[s][1]) and np.array_equal(gPF, parts[s][4])
     sh.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_device_resample_equals_the_host_planned_one(gpu_required, dtype):
+    """cslam_pf_resample_local (plan on the device) against weight_sums + scale + host keep[] + gather_local: the
+    same particles in the same slots, bit for bit, and the same Neff."""
+    from conan_slam_amd.pf import SingleComm, resample_particles, stratified_random
+
+    npart, nf = 512, 5
+    parts = _random_particles(npart, nf, dtype, seed=31)
+    rng = np.random.default_rng(32)
+    w = rng.uniform(0.0, 1.0, npart) ** 5
+    for p, wi in zip(parts, w):
+        p[0] = dtype(wi)
+    a = _shard_from(parts, nf, dtype)
+    b = _shard_from(parts, nf, dtype)
+    b.host_resample = True
+    select = stratified_random(npart, rng.uniform(size=npart), dtype)
+    ra = resample_particles(a, SingleComm(), int(0.75 * npart), True, select=select)
+    rb = resample_particles(b, SingleComm(), int(0.75 * npart), True, select=select)
+    assert ra[1] and rb[1] and abs(ra[0] - rb[0]) <= 1e-9 * abs(rb[0])
+    for i in range(0, npart, 37):
+        pa, pb = a.get_particle(i), b.get_particle(i)
+        for x, y in zip(pa, pb):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), i
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    a.close()
+    b.close()
