@@ -259,7 +259,9 @@ def main():
     for t in range(args.warmup):
         step(t)
     barrier()
-    eng.set_profiling(2)  # HIP events around every downdate launch of the timed region, on the engine's stream
+    # HIP events around one P-GEMM launch in eight of the timed region, on the engine's stream (an event pair costs
+    # about 11 us of stream time around the kernel it brackets, so bracketing every launch would slow the loop by 9 %)
+    eng.set_profiling(3)
     barrier()
     t0 = time.perf_counter()
     for t in range(args.warmup, total_steps):
@@ -292,7 +294,7 @@ def main():
         # the engine's deferred-downdate mode (P = Ps - Wp Wp^T, one P-GEMM per 128 pending columns = 2 steps here):
         # same kernels otherwise, final flush inside the timed region, the filter simply continues
         eng.set_deferred(128)
-        eng.set_profiling(2)
+        eng.set_profiling(3)
         barrier()
         t1 = time.perf_counter()
         for t in range(total_steps, total_steps + extra_steps):
