@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libslam_oracle.so")
+# SLAM_ORACLE_LIB: an alternative build of the same sources (e.g. `make -C oracle asan` for the sanitizer run)
+_LIB_PATH = os.environ.get("SLAM_ORACLE_LIB") or os.path.join(_HERE, "_build", "libslam_oracle.so")
 
 Q_LOWER_CHOL_GAIN = 1
 Q_PREDICT_NM4 = 2

@@ -181,3 +181,26 @@ def test_two_rank_resample_over_gloo(tmp_path, skew, expect):
         assert np.array_equal(got_ids, keep) and np.allclose(got_w, 1.0 / n)
     else:
         assert np.array_equal(got_ids, np.arange(n)) and np.allclose(got_w, wref, rtol=1e-6)
+
+
+def test_vectorised_strata_positions_equal_the_reference_loop():
+    """stratified_random is a running sum in the particle dtype (PF.cpp:579-596): the vectorised form must reproduce
+    the loop's roundings bit for bit."""
+    from conan_slam_amd.pf import stratified_random
+
+    def loop(n, uniforms, dtype):
+        t = np.dtype(dtype).type
+        k = t(1) / t(n)
+        out = np.empty(n, dtype=dtype)
+        di = k / t(2)
+        for i in range(n):
+            if i > 0:
+                di = t(di + k)
+            out[i] = t(di + (t(uniforms[i]) * k - k / t(2)))
+        return out
+
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64):
+        for n in (1, 2, 7, 64, 512, 4097):
+            u = rng.uniform(size=n)
+            assert np.array_equal(loop(n, u, dt), stratified_random(n, u, dt))
