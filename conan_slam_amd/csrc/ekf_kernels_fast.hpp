@@ -367,9 +367,9 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
         sflg[0] = 0;
         sflg[1] = 0;
     }
-    if (tid < K)
+    if (tid >= k && tid < K)
     {
-        V[tid] = (T)0;
+        V[tid] = (T)0; // padding entries only: observe_model below writes [0, k) (no barrier needed in between)
     }
 #pragma unroll
     for (int it = 0; it < (K * LD + 255) / 256; it++)
@@ -381,12 +381,14 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
         }
     }
     // The rows of PHT that H touches.  Normal path: the compact block written by the gather kernel, contiguous and
-    // independent of the observation model (issued before it).  Without it (deferred downdates correct PHT after
-    // the gather): rows 0..2 here, the landmark rows after observe_model.
+    // independent of the observation model: its loads are issued first, the observation model (its own dependent
+    // loads, sqrt/atan2) runs while they are in flight, then they are parked in LDS -- one barrier for both.
+    // Without the block (deferred downdates correct PHT after the gather): rows 0..2 here, the landmark rows after
+    // observe_model.
+    constexpr int NS = ((3 + K) * K + 255) / 256;
+    T             sv[NS];
     if (a.sub != nullptr)
     {
-        constexpr int NS = ((3 + K) * K + 255) / 256;
-        T             sv[NS];
 #pragma unroll
         for (int it = 0; it < NS; it++)
         {
@@ -395,6 +397,22 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
             const bool in   = (slot < 3 + k) && (c < k);
             sv[it]          = a.sub[in ? slot * k + c : 0];
         }
+    }
+    else if (tid < K && tid < k)
+    {
+        const T* p       = a.PHT + (size_t)tid * a.ldw;
+        sub[0 * LD + tid] = p[0];
+        sub[1 * LD + tid] = p[1];
+        sub[2 * LD + tid] = p[2];
+    }
+    for (int o = tid; o < a.m; o += 256)
+    {
+        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    if (a.sub != nullptr)
+    {
 #pragma unroll
         for (int it = 0; it < NS; it++)
         {
@@ -405,20 +423,6 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
                 sub[slot * LD + c] = sv[it];
             }
         }
-    }
-    else if (tid < K && tid < k)
-    {
-        const T* p       = a.PHT + (size_t)tid * a.ldw;
-        sub[0 * LD + tid] = p[0];
-        sub[1 * LD + tid] = p[1];
-        sub[2 * LD + tid] = p[2];
-    }
-    __syncthreads();
-    for (int o = tid; o < a.m; o += 256)
-    {
-        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
-        a.dV[2 * o]     = V[2 * o];
-        a.dV[2 * o + 1] = V[2 * o + 1];
     }
     __syncthreads();
     stamp(6);
