@@ -60,6 +60,8 @@ struct EkfBase
     virtual int debug_last_update(void* PHT, void* S, void* G, void* W1, void* V, int* k)      = 0;
     virtual int set_deferred(int max_cols)                                                     = 0;
     virtual int do_flush()                                                                     = 0;
+    virtual int resolve_predict()                                                              = 0;
+    virtual void set_fuse_predict(int on)                                                      = 0;
 };
 
 template <typename T>
@@ -156,6 +158,7 @@ struct Ekf : EkfBase
         (void)hipFree(dHwIds);
         (void)hipFree(dTicket);
         (void)hipFree(dPredictDone);
+        (void)hipFree(dPred);
         (void)hipFree(dAssoc);
         (void)hipFree(dAssocOut);
         (void)hipFree(dW1);
@@ -669,13 +672,22 @@ struct Ekf : EkfBase
     }
 
     // ---------------------------------------------------------------- predict (EKF.cpp:406-455)
+    // A predict() is accepted and held back: if the next call is a batch update on the fast path (f32, 16 < k <= 64,
+    // nothing pending), its gather / factor / gain kernels apply it on the fly and commit it (PredictArgs in
+    // ekf_kernels.hpp) and the predict launch disappears; every other consumer of X or P launches it first
+    // (resolve_predict).  CSLAM_FUSE_PREDICT=0 launches every predict at once.
+    PredictArgs<T> pp{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
+    T*             dPred = nullptr; // 16 scalars: factor kernel -> gain kernel (see FactorArgs::pred_out)
+    bool           fuse_now = false; // the batch in flight consumes pp
+    int            fuse_predict = 1;
+
     int predict(double v, double swa, const void* Qv, double wb, double dt) override
     {
         if (!Qv)
         {
             return fail(CSLAM_ERR_BAD_ARG, "predict: Q is null");
         }
-        int rc = use_device();
+        int rc = resolve_predict(); // two predicts in a row: the first one runs now
         if (rc)
         {
             return rc;
@@ -686,16 +698,38 @@ struct Ekf : EkfBase
         {
             w = (quirks & CSLAM_Q_PREDICT_NM4) ? (n - 4) : (n - 3);
         }
+        pp = PredictArgs<T>{1, (T)v, (T)swa, Q[0], Q[1], Q[2], Q[3], (T)wb, (T)dt, std::max(w, 0)};
+        if (!fuse_predict || sizeof(T) != 4)
+        {
+            return resolve_predict();
+        }
+        return CSLAM_OK;
+    }
+
+    void set_fuse_predict(int on) override { fuse_predict = on; }
+
+    int resolve_predict() override
+    {
+        if (!pp.valid)
+        {
+            return CSLAM_OK;
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        pp.valid = 0;
         if (kp > 0) // pose rows of the pending panels move with the pose (before anything changes X[2])
         {
             const int fix_last = (n > 3 && (quirks & CSLAM_Q_PREDICT_NM4)) ? 1 : 0;
-            hipLaunchKernelGGL(ekf_pending_predict_kernel<T>, dim3(1), dim3(256), 0, stream, dX, dP, ldp, n, (T)v, (T)swa,
-                               (T)dt, dW1, ldp, kp, fix_last);
+            hipLaunchKernelGGL(ekf_pending_predict_kernel<T>, dim3(1), dim3(256), 0, stream, dX, dP, ldp, n, pp.v, pp.swa,
+                               pp.dt, dW1, ldp, kp, fix_last);
             CSLAM_HIP_TRY(hipGetLastError());
         }
         // stripe on many CUs + Pvv/pose by the last block to finish, one launch (w = 0: one block, Pvv/pose only)
-        hipLaunchKernelGGL(ekf_predict_stripe_kernel<T>, dim3(std::max(1, (w + 255) / 256)), dim3(256), 0, stream, dX, dP,
-                           ldp, (T)v, (T)swa, Q[0], Q[1], Q[2], Q[3], (T)wb, (T)dt, std::max(w, 0), lower, dPredictDone);
+        hipLaunchKernelGGL(ekf_predict_stripe_kernel<T>, dim3(std::max(1, (pp.w + 255) / 256)), dim3(256), 0, stream, dX, dP,
+                           ldp, pp.v, pp.swa, pp.q00, pp.q10, pp.q01, pp.q11, pp.wb, pp.dt, pp.w, lower, dPredictDone);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -730,6 +764,10 @@ struct Ekf : EkfBase
         a.dL       = nullptr;
         a.dRdiag   = nullptr;
         solve_gain = false;
+        a.pp       = fuse_now ? pp : PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
+        a.P3       = dP;
+        a.ldp3     = ldp;
+        a.pred_out = dPred;
         a.lds_S    = 1;
         a.lds_G    = 1;
         {
@@ -878,6 +916,17 @@ struct Ekf : EkfBase
         {
             return rc;
         }
+        // a pending predict() rides along when this batch takes the fast path with nothing else pending
+        fuse_now = pp.valid && sizeof(T) == 4 && !keep_pending && kp == 0 && k > 16 && k <= 64 && tune_factor == 0 &&
+                   tune_gain == 0;
+        if (pp.valid && !fuse_now && (rc = resolve_predict()))
+        {
+            return rc;
+        }
+        if (fuse_now && dPred == nullptr)
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dPred, 16 * sizeof(T)));
+        }
         if (kp + k > std::max(wcap, 0) || (kp > 0 && kp + k > std::max(defer_max, kp_call_limit)))
         {
             if ((rc = flush()))
@@ -898,8 +947,9 @@ struct Ekf : EkfBase
         const dim3 ggrid((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs);
         // the compact H-rows block for the MFMA factor kernel (f32, 16 < k <= 64, no pending panels to correct)
         sub_valid = (sizeof(T) == 4 && k > 16 && k <= 64 && kp == 0 && tune_factor == 0 && dSub != nullptr);
+        PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
         hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp, lower,
-                           sub_valid ? dSub : nullptr);
+                           sub_valid ? dSub : nullptr, fuse_now ? pp : pnone);
         CSLAM_HIP_TRY(hipGetLastError());
         if (kp > 0) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T
         {
@@ -918,6 +968,11 @@ struct Ekf : EkfBase
             (rc = prof_begin(CSLAM_STAGE_GAIN)) || (rc = launch_gain(k)) || (rc = prof_end(CSLAM_STAGE_GAIN)))
         {
             return rc;
+        }
+        if (fuse_now) // the gain kernel committed the predicted pose, stripe and Pvv
+        {
+            pp.valid = 0;
+            fuse_now = false;
         }
         kp += k;
         const bool deferring = keep_pending || defer_max > 0;
@@ -1038,6 +1093,10 @@ struct Ekf : EkfBase
         if (batch)
         {
             return batch_on_device(dZ, dIdf, m, R, false);
+        }
+        if ((rc = resolve_predict()))
+        {
+            return rc;
         }
         // EKF.cpp:457-479: m successive rank-2 updates, relinearised on the updated state each time.  Their m
         // rank-2 downdates are deferred and applied by ONE P-GEMM with k = 2m at the end of the call: each
@@ -1443,7 +1502,8 @@ bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot)
         return false; // du is produced by the tuned factor kernels only
     }
     hipLaunchKernelGGL((ekf_panel_mfma_f32<false, true>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n,
-                       k, k, dGt, k, dU, slot, ldp, dX);
+                       k, k, dGt, k, dU, slot, ldp, dX, fuse_now ? (const float*)dPred : (const float*)nullptr, pp.w, dP, ldp,
+                       lower);
     return true;
 }
 
@@ -1589,6 +1649,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     {
         b->tune_downdate = atoi(tv);
     }
+    if (const char* fp = getenv("CSLAM_FUSE_PREDICT"))
+    {
+        b->set_fuse_predict(atoi(fp));
+    }
     if (const char* tg = getenv("CSLAM_TUNE_GAIN"))
     {
         b->tune_gain = atoi(tg);
@@ -1644,18 +1708,30 @@ int cslam_ekf_set_sync_mode(cslam_ekf_t h, int sync_mode)
 int cslam_ekf_set_state(cslam_ekf_t h, const void* X, int n, const void* P, int ldp)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->set_state(X, n, P, ldp);
 }
 
 int cslam_ekf_get_state(cslam_ekf_t h, void* X, void* P, int ldp)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->get_state(X, P, ldp);
 }
 
 int cslam_ekf_get_x(cslam_ekf_t h, void* X, int capacity)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->get_x(X, capacity);
 }
 
@@ -1673,12 +1749,20 @@ int cslam_ekf_get_n(cslam_ekf_t h, int* n)
 int cslam_ekf_trace(cslam_ekf_t h, double* trace)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->trace(trace);
 }
 
 int cslam_ekf_synchronize(cslam_ekf_t h)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     CSLAM_HIP_TRY(hipSetDevice(B(h)->device));
     CSLAM_HIP_TRY(hipStreamSynchronize(B(h)->stream));
     return CSLAM_OK;
@@ -1711,6 +1795,10 @@ int cslam_ekf_update_device(cslam_ekf_t h, const void* dZ, int m, const void* R,
 int cslam_ekf_augment(cslam_ekf_t h, const void* Z, int q, const void* R)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->augment(Z, q, R);
 }
 
@@ -1718,12 +1806,20 @@ int cslam_ekf_associate(cslam_ekf_t h, const void* Z, int m, const void* R, doub
                         int* kind_out)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->associate(Z, m, R, gate1, gate2, idf_out, kind_out);
 }
 
 int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->observe_heading(phi, use_heading);
 }
 
@@ -1742,18 +1838,30 @@ int cslam_ekf_get_stage_times(cslam_ekf_t h, double* ms_sum, int* launches)
 int cslam_ekf_set_deferred(cslam_ekf_t h, int max_pending_columns)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->set_deferred(max_pending_columns);
 }
 
 int cslam_ekf_flush(cslam_ekf_t h)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->do_flush();
 }
 
 int cslam_ekf_debug_last_update(cslam_ekf_t h, void* PHT, void* S, void* G, void* W1, void* V, int* k)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->resolve_predict())
+    {
+        return rc;
+    }
     return B(h)->debug_last_update(PHT, S, G, W1, V, k);
 }
 

@@ -51,14 +51,15 @@ __device__ inline T p_sym(const T* __restrict__ P, int ldp, int i, int j, int lo
 // coef[5..9] = row 1; v = innovation (EKF.cpp:117-118, bearing wrapped); fx = 0-based index of the
 // feature's x in the state (= fpos-1 of the reference).
 template <typename T>
-__device__ inline void observe_model(const T* __restrict__ X, int n, int idf, T zr, T zb, T* coef, T* v, int* fx)
+__device__ inline void observe_model_pose(const T* __restrict__ X, int n, int idf, T zr, T zb, T px, T py, T pphi, T* coef,
+                                          T* v, int* fx)
 {
     int f = 3 + 2 * idf - 2;
     *fx   = f;
     if (n > 3)
     {
-        T dx  = X[f] - X[0];
-        T dy  = X[f + 1] - X[1];
+        T dx  = X[f] - px;
+        T dy  = X[f + 1] - py;
         T d2  = dx * dx + dy * dy;
         T d   = dsqrt(d2);
         T xd  = dx / d;
@@ -76,7 +77,7 @@ __device__ inline void observe_model(const T* __restrict__ X, int n, int idf, T 
         coef[8] = -yd2;
         coef[9] = xd2;
         v[0]    = zr - d;
-        v[1]    = pi2pi<T>(zb - (datan2(dy, dx) - X[2]));
+        v[1]    = pi2pi<T>(zb - (datan2(dy, dx) - pphi));
     }
     else
     {
@@ -86,6 +87,131 @@ __device__ inline void observe_model(const T* __restrict__ X, int n, int idf, T 
         }
         v[0] = zr;
         v[1] = pi2pi<T>(zb);
+    }
+}
+
+template <typename T>
+__device__ inline void observe_model(const T* __restrict__ X, int n, int idf, T zr, T zb, T* coef, T* v, int* fx)
+{
+    observe_model_pose<T>(X, n, idf, zr, zb, X[0], X[1], X[2], coef, v, fx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A predict() that has been accepted but not launched yet (EKF.cpp:406-455): when the next call is a batch update on
+// the fast path, its three kernels apply it on the fly -- the gather and the factor kernel see the predicted pose and
+// the predicted pose rows of P, the gain kernel writes them back -- and the predict launch disappears.
+// valid = 0: nothing pending (all helpers reduce to the stored state).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct PredictArgs
+{
+    int valid;
+    T   v, swa, q00, q10, q01, q11, wb, dt;
+    int w; // stripe width: n-4 (REF_EXACT, quirk #2) or n-3
+};
+
+// predicted pose (EKF.cpp:445-452)
+template <typename T>
+__device__ inline void predicted_pose(const PredictArgs<T>& pp, const T* __restrict__ X, T* px, T* py, T* pphi)
+{
+    const T x0 = X[0], x1 = X[1], x2 = X[2];
+    if (!pp.valid)
+    {
+        *px = x0;
+        *py = x1;
+        *pphi = x2;
+        return;
+    }
+    const T s = dsin(pp.swa + x2), c = dcos(pp.swa + x2);
+    *px   = x0 + pp.v * pp.dt * c;
+    *py   = x1 + pp.v * pp.dt * s;
+    *pphi = pi2pi<T>(x2 + pp.v * pp.dt * dsin(pp.swa) / pp.wb);
+}
+
+// Gv = [[1,0,g02],[0,1,g12],[0,0,1]] (EKF.cpp:419-428) from the OLD heading
+template <typename T>
+__device__ inline void predict_gv(const PredictArgs<T>& pp, T phi_old, T* g02, T* g12)
+{
+    *g02 = -pp.v * pp.dt * dsin(pp.swa + phi_old);
+    *g12 = pp.v * pp.dt * dcos(pp.swa + phi_old);
+}
+
+// one column of the cross-covariance stripe: Gv * (a0, a1, a2), dense summation order (zeros of Gv included)
+template <typename T>
+__device__ inline void predict_stripe_col(T g02, T g12, T a0, T a1, T a2, T* o0, T* o1, T* o2)
+{
+    T t0 = (T)1 * a0;
+    t0 += (T)0 * a1;
+    t0 += g02 * a2;
+    T t1 = (T)0 * a0;
+    t1 += (T)1 * a1;
+    t1 += g12 * a2;
+    T t2 = (T)0 * a0;
+    t2 += (T)0 * a1;
+    t2 += (T)1 * a2;
+    *o0 = t0;
+    *o1 = t1;
+    *o2 = t2;
+}
+
+// Pvv = Gv Pvv Gv^T + Gu Q Gu^T (EKF.cpp:430-440), column-major 3 x 3 in and out, from the OLD heading
+template <typename T>
+__device__ inline void predict_pvv(const PredictArgs<T>& pp, T phi_old, const T* Pv, T* out)
+{
+    const T v = pp.v, dt = pp.dt, swa = pp.swa, wb = pp.wb;
+    T s = dsin(swa + phi_old), c = dcos(swa + phi_old);
+    T Gv[9] = {(T)1, (T)0, (T)0, (T)0, (T)1, (T)0, -v * dt * s, v * dt * c, (T)1}; // column-major
+    T Gu[6] = {dt * c, dt * s, dt * dsin(swa) / wb, -v * dt * s, v * dt * c, v * dt * dcos(swa) / wb};
+    T Q[4]  = {pp.q00, pp.q10, pp.q01, pp.q11};
+    T t1[9], t2[9];
+    for (int cc = 0; cc < 3; cc++) // t1 = Gv*Pvv
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            for (int l = 0; l < 3; l++)
+            {
+                acc += Gv[r + 3 * l] * Pv[l + 3 * cc];
+            }
+            t1[r + 3 * cc] = acc;
+        }
+    }
+    for (int cc = 0; cc < 3; cc++) // t2 = t1*Gv^T
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            for (int l = 0; l < 3; l++)
+            {
+                acc += t1[r + 3 * l] * Gv[cc + 3 * l];
+            }
+            t2[r + 3 * cc] = acc;
+        }
+    }
+    T GuQ[6];
+    for (int cc = 0; cc < 2; cc++)
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            for (int l = 0; l < 2; l++)
+            {
+                acc += Gu[r + 3 * l] * Q[l + 2 * cc];
+            }
+            GuQ[r + 3 * cc] = acc;
+        }
+    }
+    for (int cc = 0; cc < 3; cc++)
+    {
+        for (int r = 0; r < 3; r++)
+        {
+            T acc = (T)0;
+            for (int l = 0; l < 2; l++)
+            {
+                acc += GuQ[r + 3 * l] * Gu[cc + 3 * l];
+            }
+            out[r + 3 * cc] = t2[r + 3 * cc] + acc;
+        }
     }
 }
 
@@ -100,8 +226,12 @@ template <typename T>
 __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X, const T* __restrict__ P, int ldp,
                                                           int n, const T* __restrict__ Z, const int* __restrict__ idf,
                                                           int m, T* __restrict__ PHT, int ldw, int lower,
-                                                          T* __restrict__ sub = nullptr)
+                                                          T* __restrict__ sub = nullptr,
+                                                          PredictArgs<T> pp = PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0,
+                                                                                             (T)0, (T)0, (T)0, (T)0, 0})
 {
+    // pp.valid: a predict() is pending (see PredictArgs): this kernel works on the PREDICTED pose and pose rows of P,
+    // formed on the fly from the stored ones (which the gain kernel replaces afterwards); nothing is written to X or P.
     // sub (optional, m <= 32): the (3 + 2m) x 2m block of PHT that S = H*PHT reads -- rows 0,1,2 and the two rows
     // of every observed landmark -- stored compactly as sub[slot*2m + col] (slot 3+2o+a <-> row fx_o + a), so that
     // the one-workgroup factor kernel loads 17 KB of contiguous data instead of 2000 scattered cache lines.
@@ -119,7 +249,10 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     {
         T v[2];
         int o = o0 + threadIdx.x;
-        observe_model<T>(X, n, idf[o], Z[2 * o], Z[2 * o + 1], &s_coef[threadIdx.x * 10], v, &s_fx[threadIdx.x]);
+        T px, py, pphi;
+        predicted_pose<T>(pp, X, &px, &py, &pphi);
+        observe_model_pose<T>(X, n, idf[o], Z[2 * o], Z[2 * o + 1], px, py, pphi, &s_coef[threadIdx.x * 10], v,
+                              &s_fx[threadIdx.x]);
     }
     __syncthreads();
     if (sub != nullptr)
@@ -143,6 +276,38 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         return;
     }
     T p0 = P[(size_t)0 * ldp + i], p1 = P[(size_t)1 * ldp + i], p2 = P[(size_t)2 * ldp + i];
+    T g02 = (T)0, g12 = (T)0;
+    if (pp.valid)
+    {
+        const T phi_old = X[2];
+        predict_gv<T>(pp, phi_old, &g02, &g12);
+        if (i >= 3)
+        {
+            if (i - 3 < pp.w) // column i of the stripe (= row i of the pose columns, by symmetry)
+            {
+                T o0, o1, o2;
+                predict_stripe_col<T>(g02, g12, p0, p1, p2, &o0, &o1, &o2);
+                p0 = o0;
+                p1 = o1;
+                p2 = o2;
+            }
+        }
+        else // row i of Pvv
+        {
+            T Pv[9], out[9];
+            for (int cc = 0; cc < 3; cc++)
+            {
+                for (int r = 0; r < 3; r++)
+                {
+                    Pv[r + 3 * cc] = P[(size_t)cc * ldp + r];
+                }
+            }
+            predict_pvv<T>(pp, phi_old, Pv, out);
+            p0 = out[i];
+            p1 = out[i + 3];
+            p2 = out[i + 6];
+        }
+    }
     unsigned hit = 0; // observations whose landmark owns row i
     if (sub != nullptr && i >= 3)
     {
@@ -161,6 +326,22 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         int      fx = s_fx[oo];
         T        a  = p_sym<T>(P, ldp, i, fx, lower);
         T        b  = p_sym<T>(P, ldp, i, fx + 1, lower);
+        if (pp.valid && i < 3) // pose rows of the landmark's two columns: elements of the predicted stripe
+        {
+            T o[3];
+            if (fx - 3 < pp.w)
+            {
+                predict_stripe_col<T>(g02, g12, p_sym<T>(P, ldp, 0, fx, lower), p_sym<T>(P, ldp, 1, fx, lower),
+                                      p_sym<T>(P, ldp, 2, fx, lower), &o[0], &o[1], &o[2]);
+                a = o[i];
+            }
+            if (fx + 1 - 3 < pp.w)
+            {
+                predict_stripe_col<T>(g02, g12, p_sym<T>(P, ldp, 0, fx + 1, lower), p_sym<T>(P, ldp, 1, fx + 1, lower),
+                                      p_sym<T>(P, ldp, 2, fx + 1, lower), &o[0], &o[1], &o[2]);
+                b = o[i];
+            }
+        }
         // same summation order as the dense product: columns 0,1,2,fx,fx+1 ascending
         T s0 = p0 * c[0];
         s0 += p1 * c[1];
@@ -571,6 +752,10 @@ struct FactorArgs
     const T*   sub;    // compact (3+2m) x 2m block of PHT written by ekf_gather_kernel, or nullptr
     T*         dL;     // solve mode (ekf_gain_solve_f32): the factor L (K x K) is published instead of G; or nullptr
     T*         dRdiag; // 1 / diag(L), K values
+    PredictArgs<T> pp;   // pending predict (valid = 0: none); honoured by ekf_factor_mfma_f32 only
+    const T*   P3;       // P (for Pvv) and its leading dimension, used with pp.valid
+    int        ldp3;
+    T*         pred_out; // pp.valid: {phi_old-derived g02, g12, predicted pose (3), predicted Pvv (9)} for the gain kernel
     int        lds_S; // 1: S in LDS
     int        lds_G; // 1: G in LDS
     int        textbook;

@@ -407,9 +407,35 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
     }
     for (int o = tid; o < a.m; o += 256)
     {
-        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        T px, py, pphi; // the predicted pose when a predict() is pending (PredictArgs), else the stored one
+        predicted_pose<T>(a.pp, a.X, &px, &py, &pphi);
+        observe_model_pose<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], px, py, pphi, &coef[o * 10], &V[2 * o],
+                              &fxs[o]);
         a.dV[2 * o]     = V[2 * o];
         a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    if (a.pp.valid && tid == 255)
+    {
+        // what the gain kernel needs to write the predicted pose rows back without racing on X[2]: Gv's two
+        // coefficients (from the old heading), the predicted pose, the predicted Pvv
+        const T phi_old = a.X[2];
+        T       g02, g12, px, py, pphi, Pv[9], out[9];
+        predict_gv<T>(a.pp, phi_old, &g02, &g12);
+        predicted_pose<T>(a.pp, a.X, &px, &py, &pphi);
+        for (int e = 0; e < 9; e++)
+        {
+            Pv[e] = a.P3[(size_t)(e / 3) * a.ldp3 + (e % 3)];
+        }
+        predict_pvv<T>(a.pp, phi_old, Pv, out);
+        a.pred_out[0] = g02;
+        a.pred_out[1] = g12;
+        a.pred_out[2] = px;
+        a.pred_out[3] = py;
+        a.pred_out[4] = pphi;
+        for (int e = 0; e < 9; e++)
+        {
+            a.pred_out[5 + e] = out[e];
+        }
     }
     if (a.sub != nullptr)
     {
@@ -1665,8 +1691,13 @@ template <bool SUB, bool XUPD>
 __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict__ A, int lda, int n, int kq, int nc,
                                                           const float* __restrict__ Bt, int ldb,
                                                           const float* __restrict__ u, float* __restrict__ OUT, int ldo,
-                                                          float* __restrict__ X)
+                                                          float* __restrict__ X, const float* __restrict__ pred = nullptr,
+                                                          int pred_w = 0, float* __restrict__ P = nullptr, int ldp = 0,
+                                                          int lower = 0)
 {
+    // pred != nullptr (gain, XUPD): a predict() was applied on the fly by the gather and factor kernels (PredictArgs);
+    // this kernel commits it: the column-tile-0 workgroups write the predicted stripe and Pvv into P and add the state
+    // correction to the PREDICTED pose.  pred = {g02, g12, pose (3), Pvv (9)} from the factor kernel.
     // one wave per workgroup, one 32x32 MFMA tile per wave: grid = (n_pad/32 row tiles, ceil(nc/32) column tiles).
     // Small tiles on purpose: the kernel is a latency chain (load -> MFMA -> store), so it wants many waves.
     const int  lane = threadIdx.x;
@@ -1732,7 +1763,37 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
         const int r = row0 + lj;
         if (lh == 0 && r < n)
         {
-            X[r] += xs;
+            if (pred == nullptr)
+            {
+                X[r] += xs;
+            }
+            else
+            {
+                X[r] = ((r < 3) ? pred[2 + r] : X[r]) + xs;
+                if (r >= 3)
+                {
+                    if (r - 3 < pred_w) // column r of the cross-covariance stripe, mirrored (EKF.cpp:442-443)
+                    {
+                        const float a0 = p_sym<float>(P, ldp, 0, r, lower), a1 = p_sym<float>(P, ldp, 1, r, lower),
+                                    a2 = p_sym<float>(P, ldp, 2, r, lower);
+                        float o0, o1, o2;
+                        predict_stripe_col<float>(pred[0], pred[1], a0, a1, a2, &o0, &o1, &o2);
+                        P[(size_t)r * ldp + 0] = o0;
+                        P[(size_t)r * ldp + 1] = o1;
+                        P[(size_t)r * ldp + 2] = o2;
+                        P[(size_t)0 * ldp + r] = o0;
+                        P[(size_t)1 * ldp + r] = o1;
+                        P[(size_t)2 * ldp + r] = o2;
+                    }
+                }
+                else if (r == 0)
+                {
+                    for (int e = 0; e < 9; e++)
+                    {
+                        P[(size_t)(e / 3) * ldp + (e % 3)] = pred[5 + e];
+                    }
+                }
+            }
         }
     }
 }

@@ -569,3 +569,50 @@ def test_full_size_immediate_and_deferred_pgemm_agree(gpu_required):
     assert float(np.trace(Pa.astype(np.float64))) < tr0
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("quirks", QUIRKS)
+def test_predict_fused_into_the_update_kernels(gpu_required, quirks, monkeypatch):
+    """A predict() followed by a batch update on the fast path (f32, 16 < k <= 64) is applied by the update's own
+    kernels (PredictArgs).  Same result as the separately launched predict (CSLAM_FUSE_PREDICT=0) and as the oracle,
+    including the n-4 stripe of REF_EXACT, a double predict, and readers that force the pending predict out."""
+    from conan_slam_amd import EKF
+
+    dtype = np.float32
+    N, m = 30, 12
+    X, P = make_scenario(N, dtype, seed=91, corr=0.3)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    fused = _engine(N, dtype, quirks, X, P)
+    monkeypatch.setenv("CSLAM_FUSE_PREDICT", "0")
+    plain = _engine(N, dtype, quirks, X, P)
+    monkeypatch.delenv("CSLAM_FUSE_PREDICT")
+    orc = OracleState(X, P, dtype, quirks, 0)
+    hi = OracleState(X.astype(np.float64), P.astype(np.float64), np.float64, quirks, 0)
+    rng = np.random.default_rng(5)
+    for step in range(4):
+        args = (83.33, 0.05 * step - 0.04, Q, 73.0, 0.01)
+        idf = (rng.permutation(N)[:m] + 1).astype(np.int32)
+        Z = make_obs(orc.x(), idf, dtype, seed=step)
+        for s_ in (fused, plain, orc):
+            s_.predict(*args)
+            if step == 1:
+                s_.predict(*args)          # two predicts in a row: the first is launched on its own
+        hi.predict(*args)
+        if step == 1:
+            hi.predict(*args)
+        if step == 2:
+            xa, xb = fused.get_x(), plain.get_x()   # a reader between predict and update forces the predict out
+            assert_close("X after the forced predict", xa, xb, 1e-6)  # (FMA contraction differs between the kernels)
+        for s_ in (fused, plain, orc):
+            s_.update(Z, R, idf, True)
+        hi.update(Z.astype(np.float64), R.astype(np.float64), idf, True)
+    Xf, Pf = fused.get_state()
+    Xp, Pp = plain.get_state()
+    assert_close("fused vs separate X", Xf, Xp, 1e-6)
+    assert_close("fused vs separate P", Pf, Pp, 1e-6)
+    dt = np.dtype(dtype)
+    assert_close("X", Xf, orc.x(), 4 * X_RTOL[dt], hi.x())
+    assert_close("P", Pf, orc.p(), 4 * P_RTOL[dt], hi.p(), fair=8.0)
+    fused.close()
+    plain.close()
