@@ -949,7 +949,7 @@ struct Ekf : EkfBase
         sub_valid = (sizeof(T) == 4 && k > 16 && k <= 64 && kp == 0 && tune_factor == 0 && dSub != nullptr);
         PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
         hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp, lower,
-                           sub_valid ? dSub : nullptr, fuse_now ? pp : pnone);
+                           sub_valid ? dSub : nullptr, fuse_now ? pp : pnone, fuse_now ? dPred : (T*)nullptr);
         CSLAM_HIP_TRY(hipGetLastError());
         if (kp > 0) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T
         {

@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
                                                           int m, T* __restrict__ PHT, int ldw, int lower,
                                                           T* __restrict__ sub = nullptr,
                                                           PredictArgs<T> pp = PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0,
-                                                                                             (T)0, (T)0, (T)0, (T)0, 0})
+                                                                                             (T)0, (T)0, (T)0, (T)0, 0},
+                                                          T* __restrict__ pred_out = nullptr)
 {
     // pp.valid: a predict() is pending (see PredictArgs): this kernel works on the PREDICTED pose and pose rows of P,
     // formed on the fly from the stored ones (which the gain kernel replaces afterwards); nothing is written to X or P.
@@ -306,6 +307,22 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
             p0 = out[i];
             p1 = out[i + 3];
             p2 = out[i + 6];
+            if (pred_out != nullptr && i == 0 && blockIdx.y == 0)
+            {
+                // for the factor kernel (predicted pose) and the gain kernel (which commits the predict without racing
+                // on X[2]): {g02, g12, predicted pose (3), predicted Pvv (9)}
+                T px, py, pphi;
+                predicted_pose<T>(pp, X, &px, &py, &pphi);
+                pred_out[0] = g02;
+                pred_out[1] = g12;
+                pred_out[2] = px;
+                pred_out[3] = py;
+                pred_out[4] = pphi;
+                for (int e = 0; e < 9; e++)
+                {
+                    pred_out[5 + e] = out[e];
+                }
+            }
         }
     }
     unsigned hit = 0; // observations whose landmark owns row i
@@ -755,7 +772,7 @@ struct FactorArgs
     PredictArgs<T> pp;   // pending predict (valid = 0: none); honoured by ekf_factor_mfma_f32 only
     const T*   P3;       // P (for Pvv) and its leading dimension, used with pp.valid
     int        ldp3;
-    T*         pred_out; // pp.valid: {phi_old-derived g02, g12, predicted pose (3), predicted Pvv (9)} for the gain kernel
+    const T*   pred_out; // pp.valid: {g02, g12, predicted pose (3), predicted Pvv (9)} written by the gather kernel
     int        lds_S; // 1: S in LDS
     int        lds_G; // 1: G in LDS
     int        textbook;

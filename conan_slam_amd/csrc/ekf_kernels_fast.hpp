@@ -407,35 +407,14 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
     }
     for (int o = tid; o < a.m; o += 256)
     {
-        T px, py, pphi; // the predicted pose when a predict() is pending (PredictArgs), else the stored one
-        predicted_pose<T>(a.pp, a.X, &px, &py, &pphi);
+        // the predicted pose when a predict() is pending (PredictArgs; the gather kernel left it in pred_out),
+        // else the stored one
+        const T* ps = a.pp.valid ? (a.pred_out + 2) : a.X;
+        const T  px = ps[0], py = ps[1], pphi = ps[2];
         observe_model_pose<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], px, py, pphi, &coef[o * 10], &V[2 * o],
                               &fxs[o]);
         a.dV[2 * o]     = V[2 * o];
         a.dV[2 * o + 1] = V[2 * o + 1];
-    }
-    if (a.pp.valid && tid == 255)
-    {
-        // what the gain kernel needs to write the predicted pose rows back without racing on X[2]: Gv's two
-        // coefficients (from the old heading), the predicted pose, the predicted Pvv
-        const T phi_old = a.X[2];
-        T       g02, g12, px, py, pphi, Pv[9], out[9];
-        predict_gv<T>(a.pp, phi_old, &g02, &g12);
-        predicted_pose<T>(a.pp, a.X, &px, &py, &pphi);
-        for (int e = 0; e < 9; e++)
-        {
-            Pv[e] = a.P3[(size_t)(e / 3) * a.ldp3 + (e % 3)];
-        }
-        predict_pvv<T>(a.pp, phi_old, Pv, out);
-        a.pred_out[0] = g02;
-        a.pred_out[1] = g12;
-        a.pred_out[2] = px;
-        a.pred_out[3] = py;
-        a.pred_out[4] = pphi;
-        for (int e = 0; e < 9; e++)
-        {
-            a.pred_out[5 + e] = out[e];
-        }
     }
     if (a.sub != nullptr)
     {
