@@ -630,10 +630,31 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
         P[i]  = s.pv[(size_t)i * s.np + p];
         P0[i] = P[i];
     }
-    for (int i = 0; i < m; i++)
+    // The features of up to kObsChunk observations are requested together before the (strictly sequential) pose
+    // updates consume them: one memory round trip per chunk instead of one per observation (the arithmetic and its
+    // order are untouched).  The same registers serve the likelihood loop when m <= kObsChunk.
+    constexpr int kObsChunk = 8;
+    T             xfc[kObsChunk][2], pfc[kObsChunk][4];
+    for (int base = 0; base < m; base += kObsChunk)
     {
-        T xf[2], pf[4], ZP[2], HV[6], HF[4], SF[4], SFI[4], VI[2];
-        load_feature<T>(s, p, idf[i] - 1, xf, pf);
+#pragma unroll
+        for (int j = 0; j < kObsChunk; j++)
+        {
+            if (base + j < m)
+            {
+                load_feature<T>(s, p, idf[base + j] - 1, xfc[j], pfc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kObsChunk; j++)
+        {
+            const int i = base + j;
+            if (i >= m)
+            {
+                continue;
+            }
+        T xf[2] = {xfc[j][0], xfc[j][1]}, pf[4] = {pfc[j][0], pfc[j][1], pfc[j][2], pfc[j][3]};
+        T ZP[2], HV[6], HF[4], SF[4], SFI[4], VI[2];
         compute_jacobians<T>(PX, xf, pf, R, ZP, HV, HF, SF);
         inverse_lu<T, 2>(SF, SFI);
         VI[0] = Z[2 * i] - ZP[0];
@@ -659,6 +680,7 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
             X[e]  = X[e] + dx[e];
             PX[e] = X[e];
         }
+        }
     }
     T L[9], XS[3], z[3];
 #pragma unroll
@@ -675,14 +697,34 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
     }
     // likelihood at the sampled pose (PF.cpp:343-359)
     T like = (T)1;
-    for (int i = 0; i < m; i++)
+    for (int base = 0; base < m; base += kObsChunk)
     {
-        T xf[2], pf[4], ZP[2], HV[6], HF[4], SF[4], V[2];
-        load_feature<T>(s, p, idf[i] - 1, xf, pf);
+        if (m > kObsChunk) // (otherwise the chunk loaded above is still the right one)
+        {
+#pragma unroll
+            for (int j = 0; j < kObsChunk; j++)
+            {
+                if (base + j < m)
+                {
+                    load_feature<T>(s, p, idf[base + j] - 1, xfc[j], pfc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kObsChunk; j++)
+        {
+            const int i = base + j;
+            if (i >= m)
+            {
+                continue;
+            }
+        T xf[2] = {xfc[j][0], xfc[j][1]}, pf[4] = {pfc[j][0], pfc[j][1], pfc[j][2], pfc[j][3]};
+        T ZP[2], HV[6], HF[4], SF[4], V[2];
         compute_jacobians<T>(XS, xf, pf, R, ZP, HV, HF, SF);
         V[0] = Z[2 * i] - ZP[0];
         V[1] = pi2pi<T>(Z[2 * i + 1] - ZP[1]);
         like = like * gauss_evaluate<T, 2>(V, SF);
+        }
     }
     T d1[3] = {X0[0] - XS[0], X0[1] - XS[1], pi2pi<T>(X0[2] - XS[2])};
     T d2[3] = {X[0] - XS[0], X[1] - XS[1], pi2pi<T>(X[2] - XS[2])};
