@@ -1360,7 +1360,7 @@ int Ekf<float>::launch_downdate(const float* W, int k)
     }
     else
     {
-        // shipped: persistent, symmetric, non-temporal P accesses; mirror stores only under full storage
+        // persistent symmetric kernels (tile list); mirror stores only under full storage
         int rc = ensure_tile_list(tiles);
         if (rc)
         {

@@ -1,12 +1,22 @@
 // ekf_kernels_fast.hpp -- the tuned gfx950 kernels of the update chain (same arithmetic as the general
 // kernels in ekf_kernels.hpp, which remain the path for shapes these do not cover).
 //
-//   ekf_factor_small_kernel<T,K>  k <= K <= 64: S build by the whole workgroup, then ONE wave holds the
-//                                 matrix a row per lane in registers; Cholesky and the triangular inverse
-//                                 broadcast with v_readlane instead of LDS + barriers.
-//   ekf_gain_mfma_f32             W1 = PHT*G on v_mfma_f32_32x32x2_f32, X += PHT*u fused (u = G G^T V).
-//   ekf_downdate2_f32             P -= W1*W1^T with the P tile prefetched behind the MFMA loop.
-//   ekf_predict_stripe/pose       EKF.cpp:406-455 split so that the O(n) stripe runs on many CUs.
+// Shipped path (f32, 16 < k <= 64 per update):
+//   ekf_factor_mfma_f32<K>        S build from the gather kernel's compact block, then the Cholesky factorisation and
+//                                 the triangular inverse as rank-1 updates on the matrix cores (accumulator-layout
+//                                 tiles: the pivot row is an MFMA operand vector, no broadcasts).
+//   ekf_panel_mfma_f32            W1 = PHT*G on v_mfma_f32_32x32x2_f32, X += PHT*u fused (u = G G^T V); commits a
+//                                 pending predict; also the deferred-mode correction PHT -= Wp*Y^T.
+//   ekf_downdate_psym4_f32<.,NCH> the P-GEMM P -= W1*W1^T: persistent, symmetric (block-lower storage), dynamic tile
+//                                 tickets, every memory operation issued from inside the MFMA loop; NCH = 2 (k <= 64)
+//                                 or 4 (k <= 128) chunks of 32 columns.
+//   ekf_predict_stripe_kernel     EKF.cpp:406-455 in one launch (when a predict is not absorbed by the next update).
+// Other shapes, A/B switches and earlier generations (selected by the CSLAM_TUNE_* variables, see cslam_ekf.hip):
+//   ekf_factor_small_kernel<T,K>  one wave holds the matrix a row per lane; every multiplier broadcast by v_readlane
+//                                 (k <= 16, and f64).
+//   ekf_factor_par_kernel, ekf_factor_blocked64_f32   workgroup-parallel / 2x2-blocked factorisations.
+//   ekf_gain_solve_f32            W1 by triangular substitution (no inverse): correct, slower end to end.
+//   ekf_downdate_psym3_f32, ekf_downdate_psym_f32, ekf_downdate2_f32   earlier P-GEMM generations.
 #pragma once
 
 #include <hip/hip_runtime.h>
