@@ -640,10 +640,8 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
 #pragma unroll
         for (int j = 0; j < kObsChunk; j++)
         {
-            if (base + j < m)
-            {
-                load_feature<T>(s, p, idf[base + j] - 1, xfc[j], pfc[j]);
-            }
+            // (clamped index, unconditional load: a branch per load would serialise the round trips again)
+            load_feature<T>(s, p, idf[min(base + j, m - 1)] - 1, xfc[j], pfc[j]);
         }
 #pragma unroll
         for (int j = 0; j < kObsChunk; j++)
@@ -704,10 +702,7 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
 #pragma unroll
             for (int j = 0; j < kObsChunk; j++)
             {
-                if (base + j < m)
-                {
-                    load_feature<T>(s, p, idf[base + j] - 1, xfc[j], pfc[j]);
-                }
+                load_feature<T>(s, p, idf[min(base + j, m - 1)] - 1, xfc[j], pfc[j]);
             }
         }
 #pragma unroll
@@ -950,17 +945,29 @@ __global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w
     {
         return;
     }
-    if (threadIdx.x == 0) // PF.cpp:559-563: cumulative sum, sequential, in the particle dtype
+    // PF.cpp:559-563: cumulative sum, sequential, in the particle dtype.  The weights are staged in LDS first and the
+    // running sum stays there (one lane walking global memory took 65 us for 512 particles: a dependent L2 round trip
+    // per element).
+    __shared__ T s_cum[kPfPlanMax];
+    for (int i = threadIdx.x; i < np; i += 256)
     {
-        T run = w[0];
-        cum[0] = run;
+        s_cum[i] = w[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        T run = s_cum[0];
         for (int i = 1; i < np; i++)
         {
-            run    = run + w[i];
-            cum[i] = run;
+            run      = run + s_cum[i];
+            s_cum[i] = run;
         }
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < np; i += 256)
+    {
+        cum[i] = s_cum[i]; // (kept in global memory for inspection; the search below reads LDS)
+    }
     for (int c = threadIdx.x; c < np; c += 256) // PF.cpp:565-574
     {
         const T sc = select[c];
@@ -968,7 +975,7 @@ __global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w
         while (lo < hi)
         {
             const int mid = (lo + hi) >> 1;
-            if (sc < cum[mid])
+            if (sc < s_cum[mid])
             {
                 hi = mid;
             }
