@@ -7,6 +7,7 @@
 // between them (conan_slam_amd/pf.py does that with torch.distributed over RCCL).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -59,11 +60,22 @@ struct Pf : PfBase
     T*      dPv  = nullptr;
     T*      dXF  = nullptr;
     T*      dPF  = nullptr;
-    T*      dObs = nullptr; // staging: Z (2*mcap) | normals (3*np)
-    int*    dIdx = nullptr; // staging: idf / index lists (max(mcap, np))
+    T*      dObs = nullptr; // staging: Z (2*mcap T) | idf (mcap int) | normals (3*np T), filled by one copy per call
+    int*    dIdx = nullptr; // index lists of pack/unpack (max(mcap, np))
     double* dSums = nullptr;
     T*      dRec = nullptr; // scratch for gather_local
     int     mcap = 0;
+
+    // Pinned staging ring.  The small host inputs of a call (Z, idf, normals, select) are copied into the next slot and
+    // sent with ONE asynchronous copy, so the call returns without waiting for the stream (the caller's arrays are
+    // consumed before return all the same).  The stream is drained once per lap of the ring, never per call.
+    static constexpr int kStageSlots = 16;
+    char*             hStage         = nullptr;
+    size_t            stage_slot     = 0;
+    int               stage_pos      = 0;
+    int               stage_inflight = 0;
+    std::vector<char> staged; // Z || idf bytes currently in dObs (empty = unknown)
+    double*           hInfo = nullptr;
 
     ~Pf() override
     {
@@ -85,10 +97,54 @@ struct Pf : PfBase
         (void)hipFree(dIdx);
         (void)hipFree(dSums);
         (void)hipFree(dRec);
+        (void)hipHostFree(hStage);
+        (void)hipHostFree(hInfo);
         if (stream)
         {
             (void)hipStreamDestroy(stream);
         }
+    }
+
+    size_t off_idf() const
+    {
+        return (size_t)2 * mcap * sizeof(T);
+    }
+    size_t off_normals() const
+    {
+        return off_idf() + (size_t)mcap * sizeof(int);
+    }
+    int* dIdf() const
+    {
+        return reinterpret_cast<int*>(reinterpret_cast<char*>(dObs) + off_idf());
+    }
+    T* dNormals() const
+    {
+        return reinterpret_cast<T*>(reinterpret_cast<char*>(dObs) + off_normals());
+    }
+
+    int stage_slot_for(size_t bytes, char** out)
+    {
+        if (bytes > stage_slot)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipHostFree(hStage);
+            hStage         = nullptr;
+            size_t newsz   = std::max((bytes + 4095) / 4096 * 4096, 2 * stage_slot);
+            stage_slot     = 0;
+            CSLAM_HIP_TRY(hipHostMalloc(&hStage, newsz * kStageSlots, hipHostMallocDefault));
+            stage_slot     = newsz;
+            stage_pos      = 0;
+            stage_inflight = 0;
+        }
+        if (stage_inflight == kStageSlots)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            stage_inflight = 0;
+        }
+        *out      = hStage + (size_t)stage_pos * stage_slot;
+        stage_pos = (stage_pos + 1) % kStageSlots;
+        stage_inflight++;
+        return CSLAM_OK;
     }
 
     int use_device()
@@ -116,13 +172,15 @@ struct Pf : PfBase
         {
             return CSLAM_OK;
         }
-        int newm = std::max(m, std::max(64, 2 * mcap));
+        int newm = (std::max(m, std::max(64, 2 * mcap)) + 3) / 4 * 4; // keeps the normals 16-byte aligned
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         (void)hipFree(dObs);
         (void)hipFree(dIdx);
         dObs = nullptr;
         dIdx = nullptr;
-        CSLAM_HIP_TRY(hipMalloc(&dObs, ((size_t)2 * newm + (size_t)3 * np) * sizeof(T)));
+        mcap = 0;
+        staged.clear();
+        CSLAM_HIP_TRY(hipMalloc(&dObs, ((size_t)2 * newm + (size_t)3 * np) * sizeof(T) + (size_t)newm * sizeof(int)));
         CSLAM_HIP_TRY(hipMalloc(&dIdx, (size_t)std::max(newm, np) * sizeof(int)));
         mcap = newm;
         return CSLAM_OK;
@@ -224,18 +282,51 @@ struct Pf : PfBase
         return CSLAM_OK;
     }
 
-    // stage Z (2*m) and idf (m) of one call; inputs are consumed before return
-    int stage(const void* Z, int m, const int* idf)
+    // stage Z (2*m) and idf (m) of one call, plus `extra` (the normals) when given; inputs are consumed before return.
+    // A call whose Z/idf are byte-identical to what dObs already holds (featureUpdate right after sampleProposal,
+    // PF.cpp:150-156) sends nothing.
+    int stage(const void* Z, int m, const int* idf, const void* extra = nullptr, size_t extra_bytes = 0)
     {
         int rc = ensure_m(m);
         if (rc)
         {
             return rc;
         }
-        CSLAM_HIP_TRY(hipMemcpyAsync(dObs, Z, (size_t)2 * m * sizeof(T), hipMemcpyHostToDevice, stream));
-        if (idf)
+        const size_t zb = (size_t)2 * m * sizeof(T), ib = idf ? (size_t)m * sizeof(int) : 0;
+        const bool   same = !extra && !staged.empty() && staged.size() == zb + ib && std::memcmp(staged.data(), Z, zb) == 0 &&
+                          (ib == 0 || std::memcmp(staged.data() + zb, idf, ib) == 0);
+        if (same)
         {
-            CSLAM_HIP_TRY(hipMemcpyAsync(dIdx, idf, (size_t)m * sizeof(int), hipMemcpyHostToDevice, stream));
+            return CSLAM_OK;
+        }
+        const size_t bytes = extra ? off_normals() + extra_bytes : (idf ? off_idf() + ib : zb);
+        char*        slot  = nullptr;
+        if ((rc = stage_slot_for(bytes, &slot)))
+        {
+            return rc;
+        }
+        if (zb)
+        {
+            std::memcpy(slot, Z, zb);
+        }
+        if (ib)
+        {
+            std::memcpy(slot + off_idf(), idf, ib);
+        }
+        if (extra)
+        {
+            std::memcpy(slot + off_normals(), extra, extra_bytes);
+        }
+        staged.clear();
+        CSLAM_HIP_TRY(hipMemcpyAsync(dObs, slot, bytes, hipMemcpyHostToDevice, stream));
+        staged.resize(zb + ib);
+        if (zb)
+        {
+            std::memcpy(staged.data(), Z, zb);
+        }
+        if (ib)
+        {
+            std::memcpy(staged.data() + zb, idf, ib);
         }
         return CSLAM_OK;
     }
@@ -247,17 +338,15 @@ struct Pf : PfBase
             return fail(CSLAM_ERR_BAD_ARG, "pf_sample_proposal: bad arguments");
         }
         int rc = use_device();
-        if (rc || (rc = check_idf(idf, m, "pf_sample_proposal")) || (rc = stage(Z, m, idf)))
+        if (rc || (rc = check_idf(idf, m, "pf_sample_proposal")) ||
+            (rc = stage(Z, m, idf, normals, (size_t)3 * np * sizeof(T))))
         {
             return rc;
         }
-        T* dN = dObs + (size_t)2 * mcap;
-        CSLAM_HIP_TRY(hipMemcpyAsync(dN, normals, (size_t)3 * np * sizeof(T), hipMemcpyHostToDevice, stream));
         const T* R = static_cast<const T*>(Rv);
-        hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdx, m,
-                           R[0], R[1], R[2], R[3], dN);
+        hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(), m,
+                           R[0], R[1], R[2], R[3], dNormals());
         CSLAM_HIP_TRY(hipGetLastError());
-        CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // pageable host inputs were staged asynchronously
         return CSLAM_OK;
     }
 
@@ -277,10 +366,9 @@ struct Pf : PfBase
             return rc;
         }
         const T* R = static_cast<const T*>(Rv);
-        hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), dObs, dIdx,
+        hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), dObs, dIdf(),
                            m, R[0], R[1], R[2], R[3], (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1);
         CSLAM_HIP_TRY(hipGetLastError());
-        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         return CSLAM_OK;
     }
 
@@ -307,7 +395,6 @@ struct Pf : PfBase
         hipLaunchKernelGGL(pf_add_features_kernel<T>, dim3((np + 63) / 64, q), dim3(64), 0, stream, store(), dObs, q, R[0],
                            R[1], R[2], R[3]);
         CSLAM_HIP_TRY(hipGetLastError());
-        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         nf += q;
         return CSLAM_OK;
     }
@@ -514,8 +601,15 @@ struct Pf : PfBase
             CSLAM_HIP_TRY(hipMalloc(&dKeep, (size_t)np * sizeof(int)));
             CSLAM_HIP_TRY(hipMalloc(&dEnable, sizeof(int)));
             CSLAM_HIP_TRY(hipMalloc(&dInfo, 2 * sizeof(double)));
+            CSLAM_HIP_TRY(hipHostMalloc(&hInfo, 2 * sizeof(double), hipHostMallocDefault));
         }
-        CSLAM_HIP_TRY(hipMemcpyAsync(dSel, select, (size_t)np * sizeof(T), hipMemcpyHostToDevice, stream));
+        char* slot = nullptr;
+        if ((rc = stage_slot_for((size_t)np * sizeof(T), &slot)))
+        {
+            return rc;
+        }
+        std::memcpy(slot, select, (size_t)np * sizeof(T));
+        CSLAM_HIP_TRY(hipMemcpyAsync(dSel, slot, (size_t)np * sizeof(T), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(pf_resample_plan_kernel<T>, dim3(1), dim3(256), 0, stream, dW, np, dSel, n_eff, status, dCum, dKeep,
                            dInfo, dEnable);
         CSLAM_HIP_TRY(hipGetLastError());
@@ -529,21 +623,17 @@ struct Pf : PfBase
         CSLAM_HIP_TRY(hipGetLastError());
         if (neff || did)
         {
-            double info[2] = {0.0, 0.0};
-            CSLAM_HIP_TRY(hipMemcpyAsync(info, dInfo, sizeof(info), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipMemcpyAsync(hInfo, dInfo, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
             CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            stage_inflight = 0;
             if (neff)
             {
-                *neff = info[0];
+                *neff = hInfo[0];
             }
             if (did)
             {
-                *did = info[1] != 0.0 ? 1 : 0;
+                *did = hInfo[1] != 0.0 ? 1 : 0;
             }
-        }
-        else
-        {
-            CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // `select` is pageable host memory: done with it on return
         }
         return CSLAM_OK;
     }
