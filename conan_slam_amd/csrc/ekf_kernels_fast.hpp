@@ -372,6 +372,7 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
         }
     };
     stamp(0);
+    const T r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3]; // requested here, used by the S sums two barriers on
     if (tid == 0)
     {
         sflg[0] = 0;
@@ -472,68 +473,75 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
     // A thread's 16 elements share the row r = tid & (K-1): its H coefficients are read once.
     {
         constexpr int NE = (K * K + 255) / 256;
-        const T       r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3];
         const int     r   = tid & (K - 1);
         const int     ob = r >> 1, ra = r & 1;
         const bool    rin = r < k;
         const T*      cf  = &coef[(rin ? ob : 0) * 10 + ra * 5];
         const T       c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4];
         const int     s3 = (3 + 2 * (rin ? ob : 0)) * LD;
-        // branch-free: all LDS reads of the 16 elements are issued first (clamped column), then the sums
-        T p0[NE], p1[NE], p2[NE], p3[NE], p4[NE];
+        // The thread's columns are cb, cb + CS, ...: every LDS address is a per-thread base plus a compile-time offset
+        // and the R entry is the same for all of them (CS is even).  All reads are issued first, then the sums.
+        // Columns >= k of `sub` hold finite or stale values that the final select discards.
+        constexpr int CS = 256 / K;
+        const int     cb = tid / K;
+        const int     ri = ra + 2 * (cb & 1);
+        const T       rv = (ri == 0) ? r00 : ((ri == 1) ? r10 : ((ri == 2) ? r01 : r11));
+        const T*      sb = &sub[cb];
+        const T*      sl = &sub[s3 + cb];
+        T*            so = &S[r + cb * LD];
+        T             p0[NE], p1[NE], p2[NE], p3[NE], p4[NE];
 #pragma unroll
         for (int it = 0; it < NE; it++)
         {
-            const int c  = (tid + it * 256) / K;
-            const int cc = (c < k) ? c : 0;
-            p0[it]       = sub[0 * LD + cc];
-            p1[it]       = sub[1 * LD + cc];
-            p2[it]       = sub[2 * LD + cc];
-            p3[it]       = sub[s3 + cc];
-            p4[it]       = sub[s3 + LD + cc];
+            p0[it] = sb[0 * LD + CS * it];
+            p1[it] = sb[1 * LD + CS * it];
+            p2[it] = sb[2 * LD + CS * it];
+            p3[it] = sl[CS * it];
+            p4[it] = sl[LD + CS * it];
         }
 #pragma unroll
         for (int it = 0; it < NE; it++)
         {
-            const int c  = (tid + it * 256) / K;
+            const int c  = cb + CS * it;
             T         sm = c0 * p0[it];
             sm += c1 * p1[it];
             sm += c2 * p2[it];
             sm += c3 * p3[it];
             sm += c4 * p4[it];
-            const int ri = ra + 2 * (c & 1);
-            const T   rv = (ri == 0) ? r00 : ((ri == 1) ? r10 : ((ri == 2) ? r01 : r11));
-            const T   vv = sm + (((c >> 1) == ob) ? rv : (T)0);
-            S[r + c * LD] = (rin && c < k) ? vv : ((r == c) ? (T)1 : (T)0);
+            const T vv       = sm + (((c >> 1) == ob) ? rv : (T)0);
+            const T pad      = (r == c) ? (T)1 : (T)0;
+            so[CS * it * LD] = (rin && c < k) ? vv : pad;
         }
     }
     __syncthreads();
     stamp(7);
     // makeSymmetric (slam.h:776-779): every thread owns 16 elements (r, c); it reads (r, c) and (c, r), then all
-    // write -- (x + y) * 0.5 is the same value from both sides
+    // write -- (x + y) * 0.5 is the same value from both sides.  Same constant-offset addressing as above.
     {
         constexpr int NE = (K * K + 255) / 256;
+        constexpr int CS = 256 / K;
+        const int     r  = tid & (K - 1);
+        const int     cb = tid / K;
+        T*            so = &S[r + cb * LD];
+        const T*      st = &S[cb + r * LD];
         T             sv[NE];
 #pragma unroll
         for (int it = 0; it < NE; it++)
         {
-            const int e = tid + it * 256;
-            const int r = e & (K - 1);
-            const int c = e / K;
-            const T   x = S[r + c * LD], y = S[c + r * LD];
+            const int c = cb + CS * it;
+            const T   x = so[CS * it * LD], y = st[CS * it];
             sv[it]      = (r > c) ? (x + y) * (T)0.5 : ((r < c) ? (y + x) * (T)0.5 : (x + x) * (T)0.5);
         }
         __syncthreads();
+        T* go = a.dS + r + (size_t)cb * k;
 #pragma unroll
         for (int it = 0; it < NE; it++)
         {
-            const int e = tid + it * 256;
-            const int r = e & (K - 1);
-            const int c = e / K;
-            S[r + c * LD] = sv[it];
+            const int c      = cb + CS * it;
+            so[CS * it * LD] = sv[it];
             if (r < k && c < k)
             {
-                a.dS[r + c * k] = sv[it];
+                go[(size_t)CS * it * k] = sv[it];
             }
         }
     }
