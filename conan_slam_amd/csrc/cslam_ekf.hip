@@ -84,6 +84,7 @@ struct Ekf : EkfBase
     T*   dL    = nullptr; // solve mode: the factor L (64 x 64) and 1/diag(L) (64) of the last update
     T*   dRdiag = nullptr;
     bool solve_gain = false; // the last factor launch published L instead of G (ekf_gain_solve_f32 follows)
+    bool g_from_gt  = false; // the last factor launch wrote only G^T (ekf_factor_mfma_f32): debug transposes it
     int  solve_K    = 0;
     bool sub_valid = false;
     T*   dGt   = nullptr;
@@ -764,6 +765,7 @@ struct Ekf : EkfBase
         a.dL       = nullptr;
         a.dRdiag   = nullptr;
         solve_gain = false;
+        g_from_gt  = false;
         a.pp       = fuse_now ? pp : PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
         a.P3       = dP;
         a.ldp3     = ldp;
@@ -838,7 +840,8 @@ struct Ekf : EkfBase
                     {
                         hipLaunchKernelGGL((ekf_factor_mfma_f32<64>), dim3(1), dim3(256), 0, stream, a, dU);
                     }
-                    launched = true;
+                    launched  = true;
+                    g_from_gt = true;
                 }
             }
             // register-resident factorisation with v_readlane broadcasts
@@ -1024,6 +1027,7 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMemcpyAsync(dG, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         CSLAM_HIP_TRY(hipMemcpyAsync(dGt, Gt.data(), Gt.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         solve_gain = false; // the fallback gain is a general matrix: apply it with the product kernel
+        g_from_gt  = false;
         CSLAM_HIP_TRY(hipMemcpyAsync(dt_, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         std::vector<T> u((size_t)k, (T)0);
         for (int q = 0; q < k; q++)
@@ -1267,9 +1271,23 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipMemcpyAsync(S, dS, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
         }
-        if (G && !solve_gain)
+        if (G && !solve_gain && !g_from_gt)
         {
             CSLAM_HIP_TRY(hipMemcpyAsync(G, dG, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
+        }
+        if (G && !solve_gain && g_from_gt)
+        {
+            std::vector<T> Gt((size_t)k * k);
+            CSLAM_HIP_TRY(hipMemcpyAsync(Gt.data(), dGt, Gt.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            T* out = static_cast<T*>(G);
+            for (int c = 0; c < k; c++)
+            {
+                for (int r = 0; r < k; r++)
+                {
+                    out[(size_t)c * k + r] = Gt[(size_t)r * k + c];
+                }
+            }
         }
         if (G && solve_gain)
         {

@@ -770,28 +770,27 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
         }
         return;
     }
-    // outputs: G, G^T (coalesced), t = G^T V, u = G t.   G[r][c]: REF_EXACT G = inv(L) = X, TEXTBOOK G = X^T
+    // outputs: G^T (what the gain kernel reads; the debug entry point transposes it back), t = G^T V, u = G t.
+    // G[r][c]: REF_EXACT G = inv(L) = X, TEXTBOOK G = X^T
     const int gr = a.textbook ? LD : 1, gc = a.textbook ? 1 : LD;
     {
         constexpr int NE = (K * K + 255) / 256;
-        T             g1[NE], g2[NE];
+        constexpr int CS = 256 / K;
+        const int     x  = tid & (K - 1), yb = tid / K;
+        const T*      gp = &Gm[yb * gr + x * gc];
+        T*            go = a.dGt + x + (size_t)yb * k;
+        T             g2[NE];
 #pragma unroll
         for (int it = 0; it < NE; it++)
         {
-            const int e = tid + it * 256;
-            const int x = e & (K - 1), y = e / K;
-            g1[it]      = Gm[x * gr + y * gc]; // G[x][y]
-            g2[it]      = Gm[y * gr + x * gc]; // G[y][x]
+            g2[it] = gp[CS * it * gr]; // G[y][x], y = yb + CS it
         }
 #pragma unroll
         for (int it = 0; it < NE; it++)
         {
-            const int e = tid + it * 256;
-            const int x = e & (K - 1), y = e / K;
-            if (x < k && y < k)
+            if (x < k && yb + CS * it < k)
             {
-                a.dG[x + y * k]  = g1[it];
-                a.dGt[x + y * k] = g2[it]; // Gt[x][y] = G[y][x]
+                go[(size_t)CS * it * k] = g2[it]; // Gt[x][y] = G[y][x]
             }
         }
     }
