@@ -45,8 +45,8 @@ def parse_args():
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--pf-obs", type=int, default=8)
     ap.add_argument("--force-resample", action="store_true", help="pf: resample on every step (worst case exchange)")
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--landmarks", type=int, default=5000)
     ap.add_argument("--obs", type=int, default=32, help="observations per batch update (k = 2*obs)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
@@ -259,7 +259,7 @@ def main():
     for t in range(args.warmup):
         step(t)
     barrier()
-    # HIP events around one P-GEMM launch in eight of the timed region, on the engine's stream (an event pair costs
+    # HIP events around one P-GEMM launch in sixteen of the timed region, on the engine's stream (an event pair costs
     # about 11 us of stream time around the kernel it brackets, so bracketing every launch would slow the loop by 9 %)
     eng.set_profiling(3)
     barrier()

@@ -528,7 +528,7 @@ struct Ekf : EkfBase
     }
 
     // ---------------------------------------------------------------- profiling
-    // mode 1: every stage; 2: every P-GEMM launch; 3: one P-GEMM launch in eight (an event pair costs about 11 us of
+    // mode 1: every stage; 2: every P-GEMM launch; 3: one P-GEMM launch in sixteen (an event pair costs about 11 us of
     // stream time around the kernel it brackets -- rocprofv3 trace: 5.9 us before, 5.6 us after -- so the timed region
     // of the bench samples instead of bracketing every launch)
     bool prof_skip(int stage, bool begin)
@@ -545,7 +545,7 @@ struct Ekf : EkfBase
         {
             if (begin)
             {
-                prof_sampled = (prof_count++ % 8) == 0;
+                prof_sampled = (prof_count++ % 16) == 0;
             }
             return !prof_sampled;
         }

@@ -246,6 +246,43 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     {
         s_cand = 0u;
     }
+    // Everything this thread reads from P depends on the landmark ids only, not on the observation model: it is
+    // requested here, so that the P round trip and the idf -> X -> atan2 chain of the model below run side by side
+    // instead of one after the other (the kernel is a chain of dependent round trips, nothing else).
+    const int i  = blockIdx.x * 256 + threadIdx.x;
+    const int il = min(i, n - 1); // (rows past n: clamped loads, no stores)
+    int       fxe[kGatherObs];
+    T         ea[kGatherObs], eb[kGatherObs];
+    T         sa[kGatherObs][3], sb[kGatherObs][3]; // pp.valid, i < 3: rows 0..2 of the landmark's two columns
+    T         Pv[9];
+    const T   phi_old = X[2];
+#pragma unroll
+    for (int oo = 0; oo < kGatherObs; oo++)
+    {
+        fxe[oo] = 3 + 2 * idf[o0 + min(oo, no - 1)] - 2; // as observe_model_pose
+        ea[oo]  = p_sym<T>(P, ldp, il, fxe[oo], lower);
+        eb[oo]  = p_sym<T>(P, ldp, il, fxe[oo] + 1, lower);
+    }
+    T p0 = P[(size_t)0 * ldp + il], p1 = P[(size_t)1 * ldp + il], p2 = P[(size_t)2 * ldp + il];
+    if (pp.valid && i < 3)
+    {
+        for (int cc = 0; cc < 3; cc++)
+        {
+            for (int r = 0; r < 3; r++)
+            {
+                Pv[r + 3 * cc] = P[(size_t)cc * ldp + r];
+            }
+        }
+#pragma unroll
+        for (int oo = 0; oo < kGatherObs; oo++)
+        {
+            for (int r = 0; r < 3; r++)
+            {
+                sa[oo][r] = p_sym<T>(P, ldp, r, fxe[oo], lower);
+                sb[oo][r] = p_sym<T>(P, ldp, r, fxe[oo] + 1, lower);
+            }
+        }
+    }
     if ((int)threadIdx.x < no)
     {
         T v[2];
@@ -255,9 +292,9 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         observe_model_pose<T>(X, n, idf[o], Z[2 * o], Z[2 * o + 1], px, py, pphi, &s_coef[threadIdx.x * 10], v,
                               &s_fx[threadIdx.x]);
     }
-    __syncthreads();
     if (sub != nullptr)
     {
+        __syncthreads(); // s_cand = 0 above
         if ((int)threadIdx.x < m && threadIdx.x < 32)
         {
             const int id        = idf[threadIdx.x];
@@ -269,18 +306,15 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
                 atomicOr(&s_cand, 1u << threadIdx.x);
             }
         }
-        __syncthreads();
     }
-    int i = blockIdx.x * 256 + threadIdx.x;
+    __syncthreads();
     if (i >= n)
     {
         return;
     }
-    T p0 = P[(size_t)0 * ldp + i], p1 = P[(size_t)1 * ldp + i], p2 = P[(size_t)2 * ldp + i];
     T g02 = (T)0, g12 = (T)0;
     if (pp.valid)
     {
-        const T phi_old = X[2];
         predict_gv<T>(pp, phi_old, &g02, &g12);
         if (i >= 3)
         {
@@ -295,14 +329,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         }
         else // row i of Pvv
         {
-            T Pv[9], out[9];
-            for (int cc = 0; cc < 3; cc++)
-            {
-                for (int r = 0; r < 3; r++)
-                {
-                    Pv[r + 3 * cc] = P[(size_t)cc * ldp + r];
-                }
-            }
+            T out[9];
             predict_pvv<T>(pp, phi_old, Pv, out);
             p0 = out[i];
             p1 = out[i + 3];
@@ -337,25 +364,28 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
             cc &= cc - 1;
         }
     }
-    for (int oo = 0; oo < no; oo++)
+#pragma unroll
+    for (int oo = 0; oo < kGatherObs; oo++)
     {
+        if (oo >= no)
+        {
+            break;
+        }
         const T* c  = &s_coef[oo * 10];
-        int      fx = s_fx[oo];
-        T        a  = p_sym<T>(P, ldp, i, fx, lower);
-        T        b  = p_sym<T>(P, ldp, i, fx + 1, lower);
+        int      fx = fxe[oo];
+        T        a  = ea[oo];
+        T        b  = eb[oo];
         if (pp.valid && i < 3) // pose rows of the landmark's two columns: elements of the predicted stripe
         {
             T o[3];
             if (fx - 3 < pp.w)
             {
-                predict_stripe_col<T>(g02, g12, p_sym<T>(P, ldp, 0, fx, lower), p_sym<T>(P, ldp, 1, fx, lower),
-                                      p_sym<T>(P, ldp, 2, fx, lower), &o[0], &o[1], &o[2]);
+                predict_stripe_col<T>(g02, g12, sa[oo][0], sa[oo][1], sa[oo][2], &o[0], &o[1], &o[2]);
                 a = o[i];
             }
             if (fx + 1 - 3 < pp.w)
             {
-                predict_stripe_col<T>(g02, g12, p_sym<T>(P, ldp, 0, fx + 1, lower), p_sym<T>(P, ldp, 1, fx + 1, lower),
-                                      p_sym<T>(P, ldp, 2, fx + 1, lower), &o[0], &o[1], &o[2]);
+                predict_stripe_col<T>(g02, g12, sb[oo][0], sb[oo][1], sb[oo][2], &o[0], &o[1], &o[2]);
                 b = o[i];
             }
         }

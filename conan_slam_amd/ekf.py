@@ -188,7 +188,7 @@ class EKF:
 
     # ------------------------------------------------------------------ measurement / introspection
     def set_profiling(self, mode: int):
-        """0 off, 1 every stage of update(), 2 every downdate (P-GEMM) launch, 3 one downdate launch in eight."""
+        """0 off, 1 every stage of update(), 2 every downdate (P-GEMM) launch, 3 one downdate launch in sixteen."""
         check(self._L.cslam_ekf_set_profiling(self._h, C.c_int(mode)))
 
     def stage_times(self):

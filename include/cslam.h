@@ -136,7 +136,7 @@ int cslam_ekf_flush(cslam_ekf_t h);
 
 /* Per-stage device times of update() measured with HIP events on the handle's stream.
  * on = 1 starts recording (events around every stage of every update), on = 2 brackets the covariance downdate
- * (P-GEMM) launches only, on = 3 one downdate launch in eight (an event pair costs ~11 us of stream time), on = 0 stops.
+ * (P-GEMM) launches only, on = 3 one downdate launch in sixteen (an event pair costs ~11 us of stream time), on = 0 stops.
  * get: synchronises, writes the SUM of milliseconds per stage since profiling was switched on and the
  * number of launches per stage. */
 int cslam_ekf_set_profiling(cslam_ekf_t h, int on);
