@@ -788,7 +788,7 @@ struct FactorArgs
     const T*   PHT;
     int        ldw;
     T*         dS;
-    T*         dG;
+    T*         dG;   // G (k x k); ekf_factor_mfma_f32 leaves it alone and publishes only dGt (debug transposes it back)
     T*         dGt;
     T*         dV;
     T*         dt;
