@@ -386,6 +386,10 @@ def main():
                     "physically moves about half of them (traffic), so frac can exceed 1; issued MFMA flops are n^2 k "
                     "(half of the 2 n^2 k the mfma_* fields are normalised by)",
             "algorithmic_bytes_per_launch": dd_bytes,
+            # the same launch priced on the bytes it physically moved (PMC traffic): the figure to read for how close
+            # the kernel runs to the fabric
+            "physical_gbs": (traffic / dd_s / 1e9) if (traffic and dd_s > 0) else None,
+            "physical_frac": (traffic / dd_s / 1e9 / HBM_PEAK_GBS) if (traffic and dd_s > 0) else None,
             "launch_us": dd_s * 1e6,
             "launches_timed": dd_cnt,
             "k_per_launch": k_launch,
