@@ -897,8 +897,16 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipGetLastError());
             return CSLAM_OK;
         }
-        hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
-                           slot, dX);
+        if (k <= 64)
+        {
+            hipLaunchKernelGGL(ekf_gain_lds_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt,
+                               dt_, slot, dX);
+        }
+        else
+        {
+            hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
+                               slot, dX);
+        }
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }

@@ -1078,6 +1078,121 @@ __global__ void __launch_bounds__(256) ekf_gain_kernel(const T* __restrict__ PHT
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4 for k <= 64 (the f64 path and the small f32 batches): same thread mapping, same sums in the same order as
+// ekf_gain_kernel, but the kernel above is a chain of 8 + 64 dependent round trips (PHT in chunks, G^T through
+// scalar loads): 50 us at n = 2003, k = 64 in f64.  Here every PHT value of the row is requested up front and G^T
+// is staged in LDS once: two round trips, then 1024 multiply-adds per thread fed by broadcast LDS reads.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_gain_lds_kernel(const T* __restrict__ PHT, int ldw, int n, int n_pad, int k,
+                                                            const T* __restrict__ Gt, const T* __restrict__ t,
+                                                            T* __restrict__ W1, T* __restrict__ X)
+{
+    constexpr int KM = 64;
+    __shared__ T  s_g[KM * KM]; // G^T, k x k, row q contiguous
+    __shared__ T  s_part[4][64];
+    const int     ri = threadIdx.x & 63;
+    const int     cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int     i  = blockIdx.x * 64 + ri;
+    const bool    in = (i < n);
+    const int     ii = in ? i : 0;
+    T             pv[KM];
+#pragma unroll
+    for (int q0 = 0; q0 < KM; q0 += 8)
+    {
+        if (q0 < k) // (uniform: small batches request one chunk)
+        {
+#pragma unroll
+            for (int q = q0; q < q0 + 8; q++)
+            {
+                pv[q] = PHT[(size_t)((q < k) ? q : (k - 1)) * ldw + ii];
+            }
+        }
+    }
+    for (int e = threadIdx.x; e < k * k; e += 256)
+    {
+        s_g[e] = Gt[e];
+    }
+    __syncthreads();
+    const int c0 = cg * kGainCols;
+    T         xs = (T)0;
+    if (c0 < k)
+    {
+        T acc[kGainCols];
+#pragma unroll
+        for (int cc = 0; cc < kGainCols; cc++)
+        {
+            acc[cc] = (T)0;
+        }
+        if (c0 + kGainCols <= k)
+        {
+            // all 16 columns exist: plain reads, no selects (with them every LDS read was waited for on its own)
+#pragma unroll
+            for (int q = 0; q < KM; q++)
+            {
+                if (q < k)
+                {
+                    const T  p  = in ? pv[q] : (T)0;
+                    const T* gr = &s_g[q * k + c0];
+                    T        g[kGainCols];
+#pragma unroll
+                    for (int cc = 0; cc < kGainCols; cc++)
+                    {
+                        g[cc] = gr[cc];
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < kGainCols; cc++)
+                    {
+                        acc[cc] += p * g[cc];
+                    }
+                }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int q = 0; q < KM; q++)
+            {
+                if (q < k)
+                {
+                    const T  p  = in ? pv[q] : (T)0;
+                    const T* gr = &s_g[q * k + c0];
+#pragma unroll
+                    for (int cc = 0; cc < kGainCols; cc++)
+                    {
+                        const bool ok = (c0 + cc < k);
+                        const T    g  = gr[ok ? cc : 0];
+                        acc[cc] += p * (ok ? g : (T)0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < kGainCols; cc++)
+        {
+            if (c0 + cc < k)
+            {
+                if (i < n_pad)
+                {
+                    W1[(size_t)(c0 + cc) * ldw + i] = in ? acc[cc] : (T)0;
+                }
+                xs += acc[cc] * t[c0 + cc];
+            }
+        }
+    }
+    s_part[cg][ri] = xs;
+    __syncthreads();
+    if (cg == 0 && in)
+    {
+        T s = s_part[0][ri];
+        s += s_part[1][ri];
+        s += s_part[2][ri];
+        s += s_part[3][ri];
+        X[i] = X[i] + s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K5 (f32): P -= W1 * W1^T  (slam.h:260) -- the P-GEMM.
 // Workgroup = 4 waves, tile = 128 rows x 128 cols of P; wave w owns columns [32w, 32w+32) and all 128
 // rows as FOUR interleaved 32x32 MFMA tiles: MFMA column index j (the lane) <-> P rows 4j+b, b = 0..3,
