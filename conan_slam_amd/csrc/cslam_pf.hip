@@ -614,12 +614,10 @@ struct Pf : PfBase
                            dInfo, dEnable);
         CSLAM_HIP_TRY(hipGetLastError());
         const dim3 ggrid(13 + 6 * store().nf, (np + 255) / 256);
-        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 0>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable);
+        const T w_new = (T)(1.0 / (double)np);
+        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 0>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable, w_new);
         CSLAM_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 1>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable);
-        CSLAM_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(pf_set_weights_if_kernel<T>, dim3((np + 255) / 256), dim3(256), 0, stream, dW, np,
-                           (T)(1.0 / (double)np), dEnable);
+        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 1>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable, w_new);
         CSLAM_HIP_TRY(hipGetLastError());
         if (neff || did)
         {

@@ -993,8 +993,9 @@ __global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w
 // strides by np between consecutive elements.  grid = (rows, ceil(np/256)); PASS 0: tmp <- gather, PASS 1: store <- tmp.
 template <typename T, int PASS>
 __global__ void __launch_bounds__(256) pf_gather_rows_kernel(PfStore<T> s, const int* __restrict__ keep, T* __restrict__ tmp,
-                                                             const int* __restrict__ enable)
+                                                             const int* __restrict__ enable, T w_new)
 {
+    // w_new (PASS 1): the weight every resampled particle gets (PF.cpp:495-499) -- row 0 is written with it directly
     if (*enable == 0)
     {
         return;
@@ -1032,7 +1033,7 @@ __global__ void __launch_bounds__(256) pf_gather_rows_kernel(PfStore<T> s, const
     }
     else
     {
-        row[i] = tmp[(size_t)e * s.np + i];
+        row[i] = (e == 0) ? w_new : tmp[(size_t)e * s.np + i];
     }
 }
 
