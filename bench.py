@@ -7,22 +7,33 @@ observations per batch update (k = 64).  A "step" is one predict() + one batch u
 (EKF.cpp:406-455, 481-496) on synthetic inputs (conan_slam_amd/synth.py) that are already
 resident in HBM when the timed region starts; nothing returns to the host inside the timed region.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): a single EKF does not shard (one dense
-P, DESIGN.md "replicas only"), so every rank runs an independent filter instance of the same size with
-its own seed (the Monte-Carlo arrangement of BASELINE configs[4]); no data-path collective; the value
-is (sum of steps over ranks) / (max time over ranks); scaling = weak.
+  --workload ekf  (default) the headline line above; sub-records: `per_call` (median wall time of a call with X
+                  returned to the host each call), `dropin` (what INTEGRATION.md's adapter does: sync mode,
+                  host Z / idf, X read back after predict and after update), `reference_loop` (the cadence of the
+                  reference's driver, test/main.cpp:132-200: 6 x (predict + observeHeading) + update + augment).
+  --workload mc   BASELINE configs[4]: independent Monte-Carlo EKF instances x 2 000 landmarks, 8 per GPU, each on
+                  its own stream pair and host thread (cslam_ekf_run_many).
+  --workload pf   BASELINE configs[3]: FastSLAM-2, 512 particles x 1 000 features sharded over the ranks.
+
+Multi-GPU: `--gpus N` starts N ranks itself (torch.distributed.run as a child process, before anything touches
+the GPU) unless it already runs under a launcher (RANK / WORLD_SIZE set).  A single EKF does not shard (one dense
+P, DESIGN.md "replicas only"): every rank runs independent filter instances with their own seeds, no data-path
+collective; value = (sum of steps over ranks) / (max time over ranks); scaling = weak.
 
 The JSON line also carries
-  roofline      the downdate kernel (P -= W1 W1^T, slam.h:260), timed live with HIP events on the engine's
-                stream around every launch of the timed region;
-  cpu_baseline  the CPU oracle's dense-order port of the same update (oracle/slam_oracle_fast.c), timed on
-                this host on a bounded sample, rank 0 / N = 1 only.  Reported, not the target.
+  roofline      the covariance downdate kernel (P -= W1 W1^T, slam.h:260), timed live with HIP events on the stream
+                it is launched on; `achieved` prices a launch on the bytes the symmetric block-lower algorithm must
+                move (DESIGN.md 6), the full-storage figure of SURVEY 8d is a separate, clearly named field;
+  cpu_baseline  the CPU oracle's dense-order port of the same step (oracle/slam_oracle_fast.c) on one core, plus a
+                courtesy all-cores numpy/OpenBLAS row; this host, bounded sample, rank 0 / N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,16 +49,10 @@ MFMA_PEAK_TF = {"f32": 157.3, "f64": 78.6}
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", choices=["ekf", "pf"], default="ekf",
-                    help="ekf: the headline EKF update metric (default). pf: BASELINE configs[3], FastSLAM-2 observation "
-                         "steps with the particle set sharded over the ranks and the RCCL resample exchange")
-    ap.add_argument("--particles", type=int, default=512)
-    ap.add_argument("--features", type=int, default=1000)
-    ap.add_argument("--pf-obs", type=int, default=8)
-    ap.add_argument("--force-resample", action="store_true", help="pf: resample on every step (worst case exchange)")
+    ap.add_argument("--workload", choices=["ekf", "mc", "pf"], default="ekf")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--landmarks", type=int, default=5000)
+    ap.add_argument("--landmarks", type=int, default=None, help="default 5000 (ekf) / 2000 (mc)")
     ap.add_argument("--obs", type=int, default=32, help="observations per batch update (k = 2*obs)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--quirks", choices=["textbook", "ref_exact"], default="textbook",
@@ -55,54 +60,37 @@ def parse_args():
                          "first into the reference's LLT-failure no-op (DESIGN.md), so the timed loop uses TEXTBOOK")
     ap.add_argument("--sequential", action="store_true", help="batch=false (EKF.cpp:457-479)")
     ap.add_argument("--defer", type=int, default=0,
-                    help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = every update at once)")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+                    help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = engine default)")
+    ap.add_argument("--instances", type=int, default=8, help="mc: filter instances per GPU")
+    ap.add_argument("--particles", type=int, default=512)
+    ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--pf-obs", type=int, default=8)
+    ap.add_argument("--force-resample", action="store_true", help="pf: resample on every step (worst case exchange)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-deferred-extra", action="store_true",
-                    help="skip the additional deferred-mode measurement reported under 'deferred_mode'")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per_call / dropin / reference_loop sub-records")
     ap.add_argument("--stage-profile", action="store_true", help="extra untimed pass with events around every stage")
     return ap.parse_args()
 
 
-def cpu_baseline(args, dtype):
-    """Times the oracle's dense-order port on the SAME workload on this host (1 core)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from pyoracle import Oracle, REF_EXACT, TEXTBOOK  # cpu_baseline leg only
-
-    from conan_slam_amd.synth import Workload
-
-    w = Workload(args.landmarks, args.obs, dtype, seed=0)
-    o = Oracle(dtype, TEXTBOOK if args.quirks == "textbook" else REF_EXACT)
-    X, P = w.X0.copy(), w.P0.copy(order="F")
-    done, t_total = 0, 0.0
-    while done < 2 or (t_total < args.cpu_baseline_seconds and done < 50):
-        v, swa = w.controls(done)
-        Z, idf = w.observations(done)
-        t0 = time.perf_counter()
-        o.predict(X, P, w.n, v, swa, w.QE, w.wb, w.dt)
-        o.update(X, P, w.n, Z, w.RE, idf, True, fast=True)
-        dt = time.perf_counter() - t0
-        if done > 0 or args.cpu_baseline_seconds <= 0:  # the first call pays first-touch of the temporaries
-            t_total += dt
-        done += 1
-        if done >= 2 and t_total >= args.cpu_baseline_seconds:
-            break
-    timed = max(done - 1, 1)
-    return {
-        "value": timed / t_total if t_total > 0 else None,
-        "unit": "update steps/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{timed} predict+batch-update steps (after 1 untimed) of the same workload: n={w.n}, m={args.obs}, "
-                  f"{args.dtype}, dense operation order of slam.h:235-266 (oracle/slam_oracle_fast.c, gcc -O3 AVX2)",
-        "host_cpus": os.cpu_count(),
-    }
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child (nothing has touched the GPU yet)."""
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        return
+    if args.gpus <= 1:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd).returncode)
 
 
-def pf_main(args):
-    """BASELINE configs[3]: Np particles x Nf features, particles block-partitioned over the ranks (strong scaling:
-    the particle count is fixed).  A step = predict + sampleProposal + featureUpdate + resampleParticles
-    (PF.cpp:419-471, 502-544, 222-277, 473-500); the resample collectives run over torch.distributed (RCCL)."""
+def dist_setup():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +103,577 @@ def pf_main(args):
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    return rank, local_rank, world, torch, dist
+
+
+def max_over_ranks(torch, dist, value):
+    if dist is None:
+        return value
+    tt = torch.tensor([value], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline(landmarks, obs, dtype, dname, quirks_name, seconds):
+    """The oracle's dense-order port on the SAME workload on this host: one core (the reference is single-threaded),
+    plus the courtesy all-cores numpy/OpenBLAS row of SURVEY 8d.  This leg is the only place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from np_restatement import NpSlam            # cpu_baseline leg only
+    from pyoracle import Oracle, REF_EXACT, TEXTBOOK  # cpu_baseline leg only
+
+    from conan_slam_amd.synth import Workload
+
+    q = TEXTBOOK if quirks_name == "textbook" else REF_EXACT
+    w = Workload(landmarks, obs, dtype, seed=0)
+    o = Oracle(dtype, q)
+    X, P = w.X0.copy(), w.P0.copy(order="F")
+    done, t_total = 0, 0.0
+    while True:
+        v, swa = w.controls(done)
+        Z, idf = w.observations(done)
+        t0 = time.perf_counter()
+        o.predict(X, P, w.n, v, swa, w.QE, w.wb, w.dt)
+        o.update(X, P, w.n, Z, w.RE, idf, True, fast=True)
+        dt = time.perf_counter() - t0
+        if done > 0:  # the first call pays first-touch of the temporaries
+            t_total += dt
+        done += 1
+        if done >= 2 and (t_total >= seconds or done >= 51):
+            break
+    timed = done - 1
+    out = {
+        "value": timed / t_total, "unit": "update steps/s", "cores": 1, "kind": "port",
+        "sample": f"{timed} predict+batch-update steps (after 1 untimed) of the same workload: n={w.n}, m={obs}, "
+                  f"{dname}, dense operation order of slam.h:235-266 (oracle/slam_oracle_fast.c, gcc -O3 AVX2)",
+        "host_cpus": os.cpu_count(),
+    }
+    # courtesy row: the same dense algebra through numpy / OpenBLAS on all cores (oracle/np_restatement.py)
+    try:
+        s = NpSlam(dtype, q)
+        Xn, Pn = w.X0.copy(), np.array(w.P0, order="F")
+        cnt, tt, t = 0, 0.0, done
+        budget = max(3.0, seconds / 2)
+        while True:
+            v, swa = w.controls(t)
+            Z, idf = w.observations(t)
+            t0 = time.perf_counter()
+            Xn, Pn = s.predict(Xn, Pn, v, swa, w.QE, w.wb, w.dt)
+            Xn, Pn = s.update(Xn, Pn, Z, w.RE, idf, True)
+            dt = time.perf_counter() - t0
+            if cnt > 0:
+                tt += dt
+            cnt += 1
+            t += 1
+            if cnt >= 3 and (tt >= budget or cnt >= 41):
+                break
+        out["all_cores_numpy"] = {"value": (cnt - 1) / tt, "unit": "update steps/s", "cores": os.cpu_count(),
+                                  "kind": "port (numpy/OpenBLAS dense matrix products, oracle/np_restatement.py)",
+                                  "sample": f"{cnt - 1} steps after 1 untimed"}
+    except Exception as e:  # the courtesy row must never break the line
+        out["all_cores_numpy"] = {"value": None, "error": repr(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+class DeviceInputs:
+    """Controls and observations of `count` consecutive steps, generated up front and made resident in HBM."""
+
+    def __init__(self, torch, w, count):
+        m = w.m
+        self.ctrl, self.esize, self.m = [], w.dtype.itemsize, m
+        self.Zh = np.zeros((count, 2 * m), dtype=w.dtype)
+        self.Ih = np.zeros((count, m), dtype=np.int32)
+        self.phi = np.zeros(count)
+        for t in range(count):
+            self.ctrl.append(w.controls(t))
+            Z, idf = w.observations(t)
+            self.Zh[t] = Z.reshape(-1, order="F")
+            self.Ih[t] = idf
+            self.phi[t] = w.true_pose_after(t)[2] if False else w._true_pose[2]
+        self.dZ = torch.from_numpy(self.Zh).cuda()
+        self.dI = torch.from_numpy(self.Ih).cuda()
+        torch.cuda.synchronize()
+        self.zp, self.ip = self.dZ.data_ptr(), self.dI.data_ptr()
+
+    def z(self, t):
+        return self.zp + t * 2 * self.m * self.esize
+
+    def i(self, t):
+        return self.ip + t * self.m * 4
+
+
+def sym_tiles(n):
+    t = (n + 127) // 128
+    return t * (t + 1) // 2
+
+
+def pgemm_model(n, k_launch, dname, storage):
+    """Bytes one covariance-downdate launch must move and the matrix-core flops it issues."""
+    s = 4 if dname == "f32" else 8
+    k8 = ((int(round(k_launch)) + 7) // 8) * 8
+    full_bytes = 2.0 * n * n * s + 1.0 * n * k_launch * s  # SURVEY 8d: full-storage P read + written, W1 read once
+    if storage == "lower":
+        nt = sym_tiles(n)
+        chunks = 2 if k8 <= 64 else (4 if k8 <= 128 else (k8 + 63) // 64 * 2)
+        name = "ekf_downdate_psym4_f32<0,%d>" % (2 if k8 <= 64 else 4) if k8 <= 128 else "ekf_downdate_psym_f32<64,true,false>"
+        return {"kernel": name, "bytes": nt * 65536.0 * 2 + 1.0 * n * k8 * s, "flops_issued": nt * 128.0 * 128.0 * chunks * 32 * 2,
+                "full_storage_bytes": full_bytes, "n_sym_tiles": nt}
+    tiles = ((n + 127) // 128) ** 2
+    return {"kernel": "ekf_downdate_" + dname, "bytes": full_bytes, "flops_issued": tiles * 128.0 * 128.0 * k8 * 2,
+            "full_storage_bytes": full_bytes, "n_sym_tiles": None}
+
+
+def pmc_traffic(kernel, landmarks, k, dname):
+    try:
+        for e in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]:
+            if (e["kernel"], e["landmarks"], e["k"], e["dtype"]) == (kernel, landmarks, int(k), dname):
+                return e["traffic_bytes"], e.get("source", "profiles/pmc_traffic.json")
+    except Exception:
+        pass
+    return None, None
+
+
+def roofline_record(n, k_launch, dname, storage, launch_s, launches, landmarks, extra=None):
+    md = pgemm_model(n, k_launch, dname, storage)
+    traffic, tsrc = pmc_traffic(md["kernel"], landmarks, k_launch, dname)
+    ach = md["bytes"] / launch_s / 1e9 if launch_s and launch_s > 0 else None
+    tf = md["flops_issued"] / launch_s / 1e12 if launch_s and launch_s > 0 else None
+    rec = {
+        "kernel": md["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (ach / HBM_PEAK_GBS) if ach else None,
+        "traffic": traffic,
+        "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if traffic else None,
+        "algorithmic_bytes_per_launch": md["bytes"],
+        "bytes_model": ("block-lower symmetric storage: n_sym_tiles x 64 KiB read + written once, W1 panel (n x k8) read once"
+                        if storage == "lower" else "full storage: 2 n^2 s + n k s (SURVEY 8d)"),
+        "n_sym_tiles": md["n_sym_tiles"],
+        "launch_us": launch_s * 1e6 if launch_s else None, "launches_timed": launches, "k_per_launch": k_launch,
+        "mfma_tflops_issued": tf, "mfma_frac_of_peak": (tf / MFMA_PEAK_TF[dname]) if tf else None,
+        "mfma_flops_model": "issued: tiles x 128^2 x (32-column chunks x 32) x 2 (a symmetric kernel issues ~n^2 k, not 2 n^2 k)",
+        # SURVEY 8d's full-storage formula for the same launch: what a non-symmetric implementation would have to
+        # move; NOT a fraction of anything this kernel does
+        "full_storage_equivalent_gbs": md["full_storage_bytes"] / launch_s / 1e9 if launch_s and launch_s > 0 else None,
+    }
+    if extra:
+        rec.update(extra)
+    return rec
+
+
+def quantiles_ms(ts):
+    a = np.sort(np.asarray(ts)) * 1e3
+    return {"median_ms": float(np.median(a)), "p10_ms": float(a[int(0.1 * (len(a) - 1))]),
+            "p90_ms": float(a[int(0.9 * (len(a) - 1))]), "calls": int(len(a))}
+
+
+# ------------------------------------------------------------------------------------------------ EKF headline
+def ekf_main(args):
+    rank, local_rank, world, torch, dist = dist_setup()
+    dtype = np.float32 if args.dtype == "f32" else np.float64
+    N = args.landmarks or 5000
+
+    import conan_slam_amd
+    from conan_slam_amd import EKF, Q_REF_EXACT, Q_TEXTBOOK
+    from conan_slam_amd.synth import Workload
+
+    if conan_slam_amd.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+
+    extras = (world == 1 and not args.no_extras and not args.sequential)
+    n_bracket, n_call, n_drop = (64, 64, 48) if extras else (0, 0, 0)
+    total = args.warmup + args.steps
+    w = Workload(N, args.obs, dtype, seed=rank)
+    n, m, k = w.n, args.obs, 2 * args.obs
+    quirks = Q_TEXTBOOK if args.quirks == "textbook" else Q_REF_EXACT
+    eng = EKF(N, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
+    eng.set_state(w.X0, w.P0)
+    if args.defer > 0:
+        eng.set_deferred(args.defer)
+    inp = DeviceInputs(torch, w, total + n_bracket + n_call + n_drop)
+    batch = not args.sequential
+
+    def step(t):
+        v, swa = inp.ctrl[t]
+        eng.predict(v, swa, w.QE, w.wb, w.dt)
+        eng.update_device(inp.z(t), m, w.RE, inp.i(t), batch=batch)
+
+    def barrier():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for t in range(args.warmup):
+        step(t)
+    barrier()
+    # HIP events around a sample of the P-GEMM launches of the timed region, on the stream they run on (an event pair
+    # costs ~11 us of stream time around the kernel it brackets: one launch in 16, or in 4 for short runs)
+    eng.set_profiling(3 if args.steps >= 200 else 4)
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total):
+        step(t)
+    eng.flush()  # the last update's (pending) P-GEMM belongs to the timed region
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed = max_over_ranks(torch, dist, elapsed)
+    stages = eng.stage_times()
+    eng.set_profiling(0)
+    flags = eng.factor_status()
+
+    if rank != 0:
+        eng.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    storage = "full" if (os.environ.get("CSLAM_STORAGE") == "full" or args.dtype == "f64" or
+                         os.environ.get("CSLAM_TUNE_DOWNDATE", "0") not in ("0", "2", "3")) else "lower"
+    dd_ms, dd_cnt = stages["downdate"]
+    dd_s = (dd_ms / dd_cnt) * 1e-3 if dd_cnt else None
+    # columns one P-GEMM launch applies: k, or (explicit deferral / sequential) the pending columns of several updates
+    k_launch = k * max(1, args.defer // k) if args.defer > 0 else k
+    t_next = total
+    bracket = None
+    if extras:
+        # every P-GEMM launch bracketed (untimed pass, the filter simply continues): median and spread
+        eng.set_profiling(2)
+        for t in range(t_next, t_next + n_bracket):
+            step(t)
+        eng.flush()
+        st = eng.stage_times()
+        eng.set_profiling(0)
+        t_next += n_bracket
+        b_ms, b_cnt = st["downdate"]
+        bracket = {"launch_us_mean": b_ms / max(b_cnt, 1) * 1e3, "launches": b_cnt}
+        if not dd_cnt:
+            dd_s, dd_cnt = (b_ms / b_cnt) * 1e-3, b_cnt
+    out = {
+        "metric": "ekf_update_steps_per_sec",
+        "value": world * args.steps / elapsed,
+        "unit": "update steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"EKF-SLAM predict+{'batch' if batch else 'sequential'} update, {N} synthetic landmarks "
+                        f"(n={n}), m={m} observations/step (k={k}), {args.dtype}, one independent filter per GPU",
+            "landmarks": N, "n": n, "obs_per_update": m, "k": k, "gain_algebra": args.quirks,
+            "deferred_columns": args.defer,
+            "engine": "two-stream pipelined (P-GEMM of update t under the chain of update t+1)"
+                      if (args.dtype == "f32" and storage == "lower" and os.environ.get("CSLAM_PIPELINE", "1") != "0")
+                      else "single stream",
+            "parallelism": f"replicas x{world} (no collective)",
+            "baseline_config": "BASELINE.json configs[2]" if (N, args.dtype) == (5000, "f32") else
+                               ("BASELINE.json configs[1]" if (N, args.dtype) == (1000, "f64") else "custom"),
+        },
+        "roofline": roofline_record(n, k_launch, args.dtype, storage, dd_s, dd_cnt, N,
+                                    {"bracketed_pass": bracket} if bracket else None),
+        "factor_flags": flags,
+    }
+    if args.stage_profile:
+        eng.set_profiling(1)
+        for t in range(args.warmup, min(total, args.warmup + 50)):
+            step(t)
+        st = eng.stage_times()
+        eng.set_profiling(0)
+        out["stage_us"] = {name: (ms / max(cnt, 1)) * 1e3 for name, (ms, cnt) in st.items()}
+    if extras:
+        # SURVEY 8d: per-call times with X returned to the host each call (asynchronous engine, inputs in HBM)
+        ts = []
+        for t in range(t_next, t_next + n_call):
+            c0 = time.perf_counter()
+            step(t)
+            eng.get_x()
+            ts.append(time.perf_counter() - c0)
+        t_next += n_call
+        out["per_call"] = dict(quantiles_ms(ts[8:]), note="wall time of predict+update with X returned to the host "
+                               "after every call (median of the calls after 8 warm-ups); asynchronous mode, Z/idf in HBM",
+                               steps_per_sec_at_median=1e3 / quantiles_ms(ts[8:])["median_ms"])
+        # what INTEGRATION.md's adapter does per call: sync mode (host-side eigen fallback armed), host Z / idf,
+        # X read back after predict and after update (slam.h:841-847, 938-943 pass X by reference)
+        eng.set_sync_mode(True)
+        ts = []
+        for t in range(t_next, t_next + n_drop):
+            v, swa = inp.ctrl[t]
+            Zt = np.asfortranarray(inp.Zh[t].reshape(2, m, order="F"))
+            c0 = time.perf_counter()
+            eng.predict(v, swa, w.QE, w.wb, w.dt)
+            eng.get_x()
+            eng.update(Zt, w.RE, inp.Ih[t], batch=batch)
+            eng.get_x()
+            ts.append(time.perf_counter() - c0)
+        eng.set_sync_mode(False)
+        t_next += n_drop
+        q = quantiles_ms(ts[8:])
+        out["dropin"] = dict(q, value=1e3 / q["median_ms"], unit="update steps/s",
+                             note="drop-in adapter cadence: sync_mode=1, host Z/idf through cslam_ekf_update, "
+                                  "cslam_ekf_get_x after predict and after update")
+    out["trace_P_end"] = eng.trace()
+    out["factor_flags"] = eng.factor_status()
+    eng.close()
+    if extras and args.dtype == "f32":
+        out["reference_loop"] = reference_loop(args, torch, w, N, quirks)
+    if world == 1 and not args.no_cpu_baseline:
+        w.P0 = None
+        out["cpu_baseline"] = cpu_baseline(N, args.obs, dtype, args.dtype, args.quirks, args.cpu_baseline_seconds)
+        if out["cpu_baseline"]["value"]:
+            out["gpu_over_cpu_single_core"] = out["value"] / out["cpu_baseline"]["value"]
+        ac = out["cpu_baseline"].get("all_cores_numpy", {}).get("value")
+        if ac:
+            out["gpu_over_cpu_all_cores_numpy"] = out["value"] / ac
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def reference_loop(args, torch, w, N, quirks):
+    """The cadence of the reference's driver (test/main.cpp:132-200): predict + observeHeading on every control step,
+    update (m observations) + augment (1 new landmark) on every 6th."""
+    from conan_slam_amd import EKF
+    from conan_slam_amd.synth import Workload
+
+    cycles_w, cycles = 10, 150
+    w2 = Workload(N, args.obs, w.dtype, seed=0)
+    m = args.obs
+    eng = EKF(N + cycles_w + cycles + 2, dtype=w.dtype, quirks=quirks, sync_mode=False)
+    eng.set_state(w2.X0, w2.P0)
+    w2.P0 = None
+    steps = []
+    for c in range(cycles_w + cycles):
+        ctl = []
+        for s_ in range(6):
+            t = 6 * c + s_
+            v, swa = w2.controls(t)
+            pose = w2.true_pose_after(t)
+            ctl.append((v, swa, float(pose[2])))
+        w2._t_obs = None
+        # observations from the pose after the 6th control step (Workload.observations advances the true pose itself
+        # only when asked in order: it has been advanced above)
+        Z, idf = _observe(w2, 6 * c + 5)
+        Zn = np.array([[500.0 + c], [0.3]], dtype=w.dtype)
+        steps.append((ctl, Z, idf, Zn))
+    dZ = torch.from_numpy(np.stack([s[1].reshape(-1, order="F") for s in steps])).cuda()
+    dI = torch.from_numpy(np.stack([s[2] for s in steps])).cuda()
+    torch.cuda.synchronize()
+    es = w.dtype.itemsize
+
+    def cycle(c):
+        ctl, _, _, Zn = steps[c]
+        for v, swa, phi in ctl:
+            eng.predict(v, swa, w2.QE, w2.wb, w2.dt)
+            eng.observe_heading(phi, True)
+        eng.update_device(dZ.data_ptr() + c * 2 * m * es, m, w2.RE, dI.data_ptr() + c * m * 4, batch=True)
+        eng.augment(Zn, w2.RE)
+
+    for c in range(cycles_w):
+        cycle(c)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for c in range(cycles_w, cycles_w + cycles):
+        cycle(c)
+    eng.flush()
+    eng.synchronize()
+    el = time.perf_counter() - t0
+    rec = {"value": cycles / el, "unit": "observation cycles/s (= update steps/s)", "ms_per_cycle": el / cycles * 1e3,
+           "control_steps_per_sec": 6 * cycles / el, "cycles": cycles, "factor_flags": eng.factor_status(),
+           "note": "per cycle: 6 x (predict + observeHeading) + batch update (m observations) + augment (1 landmark), "
+                   "test/main.cpp:165-189; heading = rank-1 pending column, O(n)"}
+    eng.close()
+    return rec
+
+
+def _observe(w, t):
+    """Workload.observations for a step whose true pose has already been integrated (reference_loop)."""
+    from conan_slam_amd.synth import normal, splitmix64
+
+    N, m = w.N, w.m
+    s = 1000 * w.seed
+    keys = splitmix64(s + 4 + 7919 * (t + 1), np.arange(N, dtype=np.uint64))
+    pick = np.sort(np.argpartition(keys, m - 1)[:m]) if m < N else np.arange(N)
+    pose = w._true_pose
+    dx, dy = w.LM[0, pick] - pose[0], w.LM[1, pick] - pose[1]
+    nz = normal(s + 5 + 104729 * (t + 1), np.arange(2 * m, dtype=np.uint64))
+    Z = np.empty((2, m))
+    Z[0] = np.sqrt(dx * dx + dy * dy) + nz[0::2] * np.sqrt(float(w.R[0, 0]))
+    Z[1] = np.arctan2(dy, dx) - pose[2] + nz[1::2] * np.sqrt(float(w.R[1, 1]))
+    return np.asfortranarray(Z.astype(w.dtype)), (pick + 1).astype(np.int32)
+
+
+# ------------------------------------------------------------------------------------------------ Monte-Carlo
+def mc_main(args):
+    """BASELINE configs[4]: independent Monte-Carlo EKF runs x 2 000 landmarks, `--instances` per GPU, one stream pair
+    and one host thread per run (cslam_ekf_run_many); aggregate update steps/s."""
+    rank, local_rank, world, torch, dist = dist_setup()
+    import ctypes as C
+
+    import conan_slam_amd
+    from conan_slam_amd import EKF, Q_REF_EXACT, Q_TEXTBOOK, _capi
+    from conan_slam_amd.synth import Workload
+
+    if conan_slam_amd.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    dtype = np.float32 if args.dtype == "f32" else np.float64
+    N, m, I = args.landmarks or 2000, args.obs, args.instances
+    quirks = Q_TEXTBOOK if args.quirks == "textbook" else Q_REF_EXACT
+    total = args.warmup + args.steps
+    L = _capi.lib()
+    engs, dZs, dIs, n = [], [], [], 3 + 2 * N
+    for i in range(I):
+        w = Workload(N, m, dtype, seed=100 + rank * I + i)
+        e = EKF(N, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
+        e.set_state(w.X0, w.P0)
+        w.P0 = None
+        inp = DeviceInputs(torch, w, 2 * total)
+        engs.append(e)
+        dZs.append(inp)
+    w0 = Workload(N, m, dtype, seed=0, build_p=False)
+    ctrl = [w0.controls(t) for t in range(2 * total)]
+    vs = (C.c_double * (2 * total))(*[c[0] for c in ctrl])
+    sw = (C.c_double * (2 * total))(*[c[1] for c in ctrl])
+    QE = np.asfortranarray(w0.QE)
+    RE = np.asfortranarray(w0.RE)
+
+    def run(handles_idx, t0, count):
+        cnt = len(handles_idx)
+        hs = (C.c_void_p * cnt)(*[engs[i]._h for i in handles_idx])
+        zs = (C.c_void_p * cnt)(*[dZs[i].z(t0) for i in handles_idx])
+        ids = (C.c_void_p * cnt)(*[dZs[i].i(t0) for i in handles_idx])
+        voff = C.cast(C.byref(vs, t0 * 8), C.POINTER(C.c_double))
+        soff = C.cast(C.byref(sw, t0 * 8), C.POINTER(C.c_double))
+        _capi.check(L.cslam_ekf_run_many(hs, C.c_int(cnt), C.c_int(count), voff, soff, QE.ctypes.data_as(C.c_void_p),
+                                         C.c_double(w0.wb), C.c_double(w0.dt), zs, ids, C.c_int(m),
+                                         RE.ctypes.data_as(C.c_void_p), C.c_int(1)))
+
+    def sync(idx):
+        for i in idx:
+            engs[i].flush()
+        for i in idx:
+            engs[i].synchronize()
+
+    allidx = list(range(I))
+    run(allidx, 0, args.warmup)
+    sync(allidx)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    for e in engs:
+        e.set_profiling(3)
+    t0 = time.perf_counter()
+    run(allidx, args.warmup, args.steps)
+    sync(allidx)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed = max_over_ranks(torch, dist, elapsed)
+    dd = [e.stage_times()["downdate"] for e in engs]
+    for e in engs:
+        e.set_profiling(0)
+    flags = [e.factor_status() for e in engs]
+    if rank != 0:
+        for e in engs:
+            e.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    # the same number of steps on ONE instance alone (the filter simply continues)
+    run([0], total, args.warmup)
+    sync([0])
+    t1 = time.perf_counter()
+    run([0], total + args.warmup, args.steps)
+    sync([0])
+    el1 = time.perf_counter() - t1
+    dd_ms = sum(d[0] for d in dd)
+    dd_cnt = sum(d[1] for d in dd)
+    dd_s = dd_ms / dd_cnt * 1e-3 if dd_cnt else None
+    storage = "lower" if args.dtype == "f32" and os.environ.get("CSLAM_STORAGE") != "full" else "full"
+    out = {
+        "metric": "ekf_update_steps_per_sec", "value": world * I * args.steps / elapsed, "unit": "update steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{world * I} independent Monte-Carlo EKF-SLAM runs x {N} landmarks (n={n}), m={m} (k={2 * m}), "
+                               f"{args.dtype}, {I} runs per GPU, one stream pair + one host thread per run",
+                   "landmarks": N, "n": n, "obs_per_update": m, "instances_per_gpu": I, "gain_algebra": args.quirks,
+                   "parallelism": f"{I} instances/GPU x {world} GPU(s), no collective",
+                   "baseline_config": "BASELINE.json configs[4]" if (N, I * max(world, 1)) == (2000, 64) or N == 2000 else "custom"},
+        "single_instance": {"value": args.steps / el1, "unit": "update steps/s", "ms_per_step": el1 / args.steps * 1e3,
+                            "note": "one of the instances run alone on the same GPU (same driver)"},
+        "concurrency_gain": (I * args.steps / elapsed) / (args.steps / el1) if world == 1 else None,
+        "roofline": roofline_record(n, 2 * m, args.dtype, storage, dd_s, dd_cnt, N,
+                                    {"note": "P-GEMM launches of all instances (sampled 1 in 16), co-running with the "
+                                             "other instances' kernels"}),
+        "factor_flags": flags,
+    }
+    for e in engs:
+        e.close()
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, m, dtype, args.dtype, args.quirks, args.cpu_baseline_seconds)
+        out["cpu_baseline"]["note"] = "one instance on one core; the reference would run the 64 instances one after another"
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ FastSLAM-2
+def pf_cpu_baseline(Np, Nf, m, seconds):
+    """The oracle's per-particle FastSLAM-2 step (PF.cpp:419-471, 502-544, 222-277) + resample on one core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pyoracle import Oracle  # cpu_baseline leg only
+
+    from conan_slam_amd.synth import Workload, normal
+
+    dtype = np.float32
+    w = Workload(Nf, m, dtype, seed=0, build_p=False)
+    o = Oracle(dtype)
+    XF0 = np.asfortranarray(np.stack([w.X0[3::2], w.X0[4::2]]).astype(dtype))
+    PF0 = np.asfortranarray(np.tile(np.array([1, 0, 0, 1], dtype=dtype)[:, None], (1, Nf)))
+    parts = []
+    for g in range(Np):
+        pose = np.array([0.05 * normal(77, 3 * g), 0.05 * normal(77, 3 * g + 1), 0.002 * normal(77, 3 * g + 2)], dtype=dtype)
+        parts.append([np.array([1.0 / Np], dtype=dtype), pose, np.asfortranarray(np.diag([0.05, 0.05, 1e-4]).astype(dtype)),
+                      XF0.copy(order="F"), PF0.copy(order="F")])
+    done, tt = 0, 0.0
+    while True:
+        v, swa = w.controls(done)
+        Z, idf = w.observations(done)
+        nrm = normal(500 + done, np.arange(3 * Np, dtype=np.uint64)).reshape(3, Np).astype(dtype)
+        t0 = time.perf_counter()
+        for i, p in enumerate(parts):
+            o.pf_predict(p[1], p[2], v, swa, w.QE, w.wb, w.dt)
+            o.pf_sample_proposal(p[0], p[1], p[2], p[3], p[4], Z, idf, w.RE, np.ascontiguousarray(nrm[:, i]))
+            o.pf_feature_update(p[1], p[3], p[4], Z, idf, w.RE)
+        wv = np.array([p[0][0] for p in parts], dtype=dtype)
+        sel = ((np.arange(Np) + 0.5) / Np).astype(dtype)
+        _, did, keep = o.pf_normalize_resample(wv, Np + 1, True, sel)
+        new = [[np.array([wv[i]], dtype=dtype)] + [a.copy(order="F") for a in parts[keep[i]][1:]] for i in range(Np)]
+        parts = new
+        dt = time.perf_counter() - t0
+        if done > 0:
+            tt += dt
+        done += 1
+        if done >= 2 and (tt >= seconds or done >= 21):
+            break
+    return {"value": (done - 1) / tt, "unit": "PF observation steps/s", "cores": 1, "kind": "port",
+            "sample": f"{done - 1} steps (after 1 untimed): {Np} particles x {Nf} features, m={m}, per-particle oracle calls "
+                      "(oracle/slam_oracle_pf.inc) + resample with deep copies (PF.cpp:492-498), forced every step",
+            "host_cpus": os.cpu_count()}
+
+
+def pf_main(args):
+    """BASELINE configs[3]: Np particles x Nf features, particles block-partitioned over the ranks (strong scaling:
+    the particle count is fixed).  A step = predict + sampleProposal + featureUpdate + resampleParticles
+    (PF.cpp:419-471, 502-544, 222-277, 473-500); the resample collectives run over torch.distributed (RCCL)."""
+    rank, local_rank, world, torch, dist = dist_setup()
     from conan_slam_amd.pf import ParticleShard, SingleComm, TorchComm, resample_particles
     from conan_slam_amd.synth import Workload, normal, uniform01
 
@@ -132,7 +691,9 @@ def pf_main(args):
         g = rank * L + i
         pose = np.array([0.05 * normal(77, 3 * g), 0.05 * normal(77, 3 * g + 1), 0.002 * normal(77, 3 * g + 2)], dtype=dtype)
         sh.set_particle(i, 1.0 / Np, pose, Pv, XF, PF)
-    comm = TorchComm(device=torch.device("cuda", local_rank)) if world > 1 else SingleComm()
+    from conan_slam_amd.pf import RcclComm
+
+    comm = RcclComm(local_rank) if world > 1 else SingleComm()
     total = args.warmup + args.steps
     inputs = []
     for t in range(total):
@@ -165,12 +726,14 @@ def pf_main(args):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(torch, dist, elapsed)
     ws = sh.get_weights()
     if rank == 0:
-        print(json.dumps({
+        rec_bytes = (13 + 6 * Nf) * 4
+        # the resample's particle moves are the only HBM-heavy part: every kept record is read and written twice
+        # (gather through a scratch copy, pf_gather_rows_kernel): 4 x record x Np bytes per resampling step
+        moved = 4.0 * rec_bytes * Np * n_resampled
+        out = {
             "metric": "pf_observation_steps_per_sec", "value": args.steps / elapsed, "unit": "PF observation steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -178,11 +741,21 @@ def pf_main(args):
                                    f"particles sharded {L}/GPU over {world} GPU(s)",
                        "particles": Np, "features": Nf, "obs_per_step": m, "resamples": n_resampled,
                        "force_resample": bool(args.force_resample),
-                       "parallelism": f"particles/{world}; all-reduce(2) + all-gather(N) + all-to-all-v(records)",
+                       "parallelism": f"particles/{world}; RCCL all-reduce(2) + all-gather(N) + grouped send/recv(records) behind the C ABI",
                        "baseline_config": "BASELINE.json configs[3]"},
             "particle_obs_per_sec": args.steps * Np * m / elapsed,
             "weights_finite": bool(np.all(np.isfinite(ws))),
-        }), flush=True)
+            "roofline": {"kernel": "pf_gather_rows_kernel (resample moves)", "bound": "hbm", "unit": "GB/s",
+                         "peak": HBM_PEAK_GBS, "achieved": moved / elapsed / 1e9,
+                         "frac": moved / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "whole-step average: algorithmic bytes of the particle moves (4 x record x Np per resample) "
+                                 "/ step time; the step is a latency chain of small kernels, not bandwidth-bound "
+                                 "(DESIGN.md 5)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = pf_cpu_baseline(Np, Nf, m, args.cpu_baseline_seconds)
+            out["gpu_over_cpu_single_core"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
     sh.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -190,228 +763,12 @@ def pf_main(args):
 
 def main():
     args = parse_args()
+    launch_ranks_if_needed(args)
     if args.workload == "pf":
         return pf_main(args)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dtype = np.float32 if args.dtype == "f32" else np.float64
-    esize = np.dtype(dtype).itemsize
-
-    import torch
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-
-    import conan_slam_amd
-    from conan_slam_amd import EKF, Q_REF_EXACT, Q_TEXTBOOK
-    from conan_slam_amd.synth import Workload
-
-    if conan_slam_amd.device_count() == 0:
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-
-    total_steps = args.warmup + args.steps
-    # second, clearly labelled measurement on the default line: the same steps with cslam_ekf_set_deferred(128)
-    with_deferred_extra = (world == 1 and args.defer == 0 and not args.sequential and args.dtype == "f32"
-                           and not args.no_deferred_extra)
-    extra_steps = args.steps if with_deferred_extra else 0
-    w = Workload(args.landmarks, args.obs, dtype, seed=rank)
-    n, m, k = w.n, args.obs, 2 * args.obs
-    quirks = Q_TEXTBOOK if args.quirks == "textbook" else Q_REF_EXACT
-    eng = EKF(args.landmarks, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
-    eng.set_state(w.X0, w.P0)
-    if args.defer > 0:
-        eng.set_deferred(args.defer)
-    w.P0 = None  # free 400 MB of host memory
-
-    # inputs of every step, generated up front and made resident in HBM
-    ctrl = []
-    Zall = np.zeros((total_steps + extra_steps, 2 * m), dtype=dtype)
-    Iall = np.zeros((total_steps + extra_steps, m), dtype=np.int32)
-    for t in range(total_steps + extra_steps):
-        ctrl.append(w.controls(t))
-        Z, idf = w.observations(t)
-        Zall[t] = Z.reshape(-1, order="F")
-        Iall[t] = idf
-    dZ = torch.from_numpy(Zall).cuda()
-    dI = torch.from_numpy(Iall).cuda()
-    torch.cuda.synchronize()
-    zp, ip = dZ.data_ptr(), dI.data_ptr()
-    batch = not args.sequential
-
-    def step(t):
-        v, swa = ctrl[t]
-        eng.predict(v, swa, w.QE, w.wb, w.dt)
-        eng.update_device(zp + t * 2 * m * esize, m, w.RE, ip + t * m * 4, batch=batch)
-
-    def barrier():
-        eng.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    for t in range(args.warmup):
-        step(t)
-    barrier()
-    # HIP events around one P-GEMM launch in sixteen of the timed region, on the engine's stream (an event pair costs
-    # about 11 us of stream time around the kernel it brackets, so bracketing every launch would slow the loop by 9 %)
-    eng.set_profiling(3)
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(args.warmup, total_steps):
-        step(t)
-    eng.flush()  # deferred mode: the last pending panels are applied inside the timed region
-    eng.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    stages = eng.stage_times()
-    eng.set_profiling(0)
-    flags = eng.factor_status()
-    trace_end = eng.trace()
-
-    stage_profile = None
-    if args.stage_profile and rank == 0:
-        eng.set_profiling(1)
-        for t in range(args.warmup, min(total_steps, args.warmup + 50)):
-            step(t)
-        st = eng.stage_times()
-        eng.set_profiling(0)
-        stage_profile = {name: (ms / max(cnt, 1)) * 1e3 for name, (ms, cnt) in st.items()}  # us per launch
-
-    deferred_extra = None
-    if with_deferred_extra:
-        # the engine's deferred-downdate mode (P = Ps - Wp Wp^T, one P-GEMM per 128 pending columns = 2 steps here):
-        # same kernels otherwise, final flush inside the timed region, the filter simply continues
-        eng.set_deferred(128)
-        eng.set_profiling(3)
-        barrier()
-        t1 = time.perf_counter()
-        for t in range(total_steps, total_steps + extra_steps):
-            step(t)
-        eng.flush()
-        eng.synchronize()
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t1
-        st2 = eng.stage_times()
-        eng.set_profiling(0)
-        eng.set_deferred(0)
-        d_ms, d_cnt = st2["downdate"]
-        deferred_extra = {
-            "value": extra_steps / el2, "unit": "update steps/s", "ms_per_step": el2 / extra_steps * 1e3,
-            "deferred_columns": 128, "p_gemm_launches": d_cnt, "p_gemm_launch_us": d_ms / max(d_cnt, 1) * 1e3,
-            "factor_flags": eng.factor_status(),
-            "note": "cslam_ekf_set_deferred(128): every update is applied (state, and covariance through the pending-panel "
-                    "correction); the P-GEMM runs once per 128 pending W1 columns; final flush inside the timed region",
-        }
-
-    if rank != 0:
-        eng.close()
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    dd_ms, dd_cnt = stages["downdate"]
-    dd_s = (dd_ms / max(dd_cnt, 1)) * 1e-3
-    # columns one P-GEMM launch applies: k, or (deferred / sequential) the pending columns of several updates
-    k_launch = (k if batch else 2 * m) * args.steps / max(dd_cnt, 1) if args.defer > 0 else (k if batch else 2 * m)
-    # algorithmic bytes of one downdate launch: P read once + written once, W1 read once
-    dd_bytes = 2.0 * n * n * esize + 1.0 * n * k_launch * esize
-    dd_flops = 2.0 * n * n * k_launch
-    achieved = dd_bytes / dd_s / 1e9 if dd_s > 0 else None
-    tune_dd = os.environ.get("CSLAM_TUNE_DOWNDATE", "0")
-    storage = "full" if (os.environ.get("CSLAM_STORAGE") == "full" or args.dtype == "f64" or
-                         tune_dd not in ("0", "2", "3")) else "lower"
-    if args.dtype != "f32" or tune_dd in ("1", "4"):
-        kernel_name = "ekf_downdate_" + args.dtype
-    elif tune_dd == "2" or k_launch > 128 or (k_launch > 64 and storage != "lower"):
-        kernel_name = "ekf_downdate_psym_f32<64,true,%s>" % ("false" if storage == "lower" else "true")
-    elif storage == "lower" and tune_dd == "0":
-        # memory operations inside the MFMA loop (the shipped path): two chunks of 32 for k <= 64, four for k <= 128
-        kernel_name = "ekf_downdate_psym4_f32<0,%d>" % (2 if k_launch <= 64 else 4)
-    else:
-        kernel_name = "ekf_downdate_psym3_f32<%s>" % ("false,false" if storage == "lower" else "true,true")
-    traffic = None  # physical HBM bytes per launch: from the committed rocprofv3 --pmc summary of this exact configuration
-    try:
-        for e in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]:
-            if (e["kernel"], e["landmarks"], e["k"], e["dtype"]) == (kernel_name, args.landmarks, int(k_launch), args.dtype):
-                traffic = e["traffic_bytes"]
-    except Exception:
-        traffic = None
-    out = {
-        "metric": "ekf_update_steps_per_sec",
-        "value": world * args.steps / elapsed,
-        "unit": "update steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": args.dtype,
-        "data": "synthetic",
-        "config": {
-            "workload": f"EKF-SLAM predict+{'batch' if batch else 'sequential'} update, {args.landmarks} synthetic landmarks "
-                        f"(n={n}), m={m} observations/step (k={k}), {args.dtype}, one independent filter per GPU",
-            "landmarks": args.landmarks,
-            "n": n,
-            "obs_per_update": m,
-            "k": k,
-            "gain_algebra": args.quirks,
-            "deferred_columns": args.defer,
-            "parallelism": f"replicas x{world} (no collective)",
-            "baseline_config": "BASELINE.json configs[2]" if (args.landmarks, args.dtype) == (5000, "f32") else "custom",
-        },
-        "roofline": {
-            "kernel": kernel_name,
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": traffic,
-            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
-            "note": "achieved uses SURVEY 8d's full-storage algorithmic bytes (2 n^2 s + n k s); the symmetric kernel "
-                    "physically moves about half of them (traffic), so frac can exceed 1; issued MFMA flops are n^2 k "
-                    "(half of the 2 n^2 k the mfma_* fields are normalised by)",
-            "algorithmic_bytes_per_launch": dd_bytes,
-            # the same launch priced on the bytes it physically moved (PMC traffic): the figure to read for how close
-            # the kernel runs to the fabric
-            "physical_gbs": (traffic / dd_s / 1e9) if (traffic and dd_s > 0) else None,
-            "physical_frac": (traffic / dd_s / 1e9 / HBM_PEAK_GBS) if (traffic and dd_s > 0) else None,
-            "launch_us": dd_s * 1e6,
-            "launches_timed": dd_cnt,
-            "k_per_launch": k_launch,
-            "mfma_tflops_issued": dd_flops / dd_s / 1e12 if dd_s > 0 else None,
-            "mfma_frac_of_peak": (dd_flops / dd_s / 1e12 / MFMA_PEAK_TF[args.dtype]) if dd_s > 0 else None,
-        },
-        "factor_flags": flags,
-        "deferred_mode": deferred_extra,
-        "trace_P_end": trace_end,
-    }
-    if stage_profile:
-        out["stage_us"] = stage_profile
-    if world == 1 and not args.no_cpu_baseline:
-        eng.close()
-        out["cpu_baseline"] = cpu_baseline(args, dtype)
-        if out["cpu_baseline"]["value"]:
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    else:
-        eng.close()
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if args.workload == "mc":
+        return mc_main(args)
+    return ekf_main(args)
 
 
 if __name__ == "__main__":

@@ -54,10 +54,19 @@ def _preload_shared_hip_runtime():
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
             return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        cand = os.path.join(libdir, "libamdhip64.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
             hip_runtime_path = cand
+            # the same goes for RCCL (cslam_pf_resample_sharded binds it with dlopen by SONAME): torch's copy first, so
+            # that torch.distributed and the engine share one
+            rc = os.path.join(libdir, "librccl.so")
+            if os.path.exists(rc) and os.environ.get("CSLAM_PRELOAD_RCCL", "1") != "0":
+                try:
+                    C.CDLL(rc, mode=C.RTLD_GLOBAL)
+                except OSError:
+                    pass
     except Exception:
         pass  # fall back to the system runtime
 

@@ -1,8 +1,16 @@
 // cslam_ekf.hip -- host side of the EKF-SLAM engine behind the C ABI of include/cslam.h.
 //
-// One handle = one filter instance bound to one device and one HIP stream; X and P live in HBM for the
-// lifetime of the handle.  update() is a chain of four launches (gather, factor, gain, downdate) on the
-// handle's stream; nothing returns to the host unless the caller asks (get_x / get_state / sync mode).
+// One handle = one filter instance bound to one device; X and P live in HBM for the lifetime of the handle.
+// update() is a chain of launches (gather, [pending-panel correction], factor, gain, pose-stripe downdate) on the
+// handle's stream A, and the covariance downdate P -= W1 W1^T (the P-GEMM) on stream B:
+//
+//   pipelined mode (f32 block-lower default, CSLAM_PIPELINE): the covariance is held as P = Ps - Wp Wp^T with the W1
+//   panel of the LAST update (and the rank-1 columns of heading observations since) still pending.  Update t+1 gathers
+//   its columns from Ps (corrected by the pending panel), THEN the P-GEMM of panel t starts on stream B and sweeps Ps
+//   while stream A runs the serial factor / gain chain of update t+1, predicts and heading observations (which only touch
+//   the pose stripe Pv, see ekf_kernels.hpp p_get, never Ps).  Step time = gather + P-GEMM instead of the whole chain.
+//   immediate mode: every update launches its own P-GEMM behind its gain kernel on the same stream.
+// Nothing returns to the host unless the caller asks (get_x / get_state / sync mode).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -11,11 +19,14 @@
 #include <cstdint>
 #include <cstdlib>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "cslam_common.hpp"
 #include "ekf_kernels.hpp"
 #include "ekf_kernels_fast.hpp"
+#include "ekf_pose_kernels.hpp"
 #include "host_linalg.hpp"
 
 using namespace cslam;
@@ -42,7 +53,10 @@ struct EkfBase
     int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
     int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (readlane one-wave up to k=64, workgroup-parallel up to 128 in f32, general beyond), 2 general always, 3 workgroup-parallel always, 5 blocked 2x2 (f32, 32<k<=64)
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
-    hipStream_t stream   = nullptr;
+    int         pipeline      = 0; // P-GEMM of update t on stream B under the chain of update t+1 (env CSLAM_PIPELINE)
+    int         pgemm_spare   = 16; // pipelined: workgroups the persistent P-GEMM grid leaves out (env CSLAM_PGEMM_SPARE)
+    hipStream_t stream   = nullptr; // A: everything except the P-GEMM
+    hipStream_t stream_b = nullptr; // B: the P-GEMM (== stream when not pipelined)
 
     virtual int init()                                                                        = 0;
     virtual int set_state(const void* X, int n, const void* P, int ldp)                        = 0;
@@ -62,6 +76,7 @@ struct EkfBase
     virtual int do_flush()                                                                     = 0;
     virtual int resolve_predict()                                                              = 0;
     virtual void set_fuse_predict(int on)                                                      = 0;
+    virtual int sync_all()                                                                     = 0;
 };
 
 template <typename T>
@@ -69,15 +84,25 @@ struct Ekf : EkfBase
 {
     T*   dX = nullptr;
     T*   dP = nullptr;
+    T*   dPv = nullptr; // pose stripe: columns 0..2 of P (always current; see p_get in ekf_kernels.hpp)
+    T*   dWv = nullptr; // pose rows of the last update's W1 (3 x kcap), saved by the pose downdate before it zeroes them
+    int* dPoseDone = nullptr; // ticket counters: [0] ekf_pose_step_kernel, [1] ekf_pose_downdate_kernel
+    int* dSign     = nullptr; // per region: wcap column signs (heading columns with S < 0), then [2*wcap + r] their count
+    int  hd_cols[2] = {0, 0}; // heading columns appended to each region since it became the pending store
+    // the pending W1 store is two regions of wcap columns: `wcur` collects pending columns, the other one may still be
+    // read by a P-GEMM in flight on stream B
+    int        wcur = 0;
+    unsigned   inflight_mask = 0; // regions an unfinished P-GEMM reads (cleared when stream A has waited for it)
+    hipEvent_t ev_a2b = nullptr, ev_pgemm = nullptr;
+    T*         last_slot = nullptr; // W1 of the last update
     // update workspace
     int  kcap  = 0;
     T*   dPHT  = nullptr;
-    T*   dW1   = nullptr; // pending W1 panels, ldp x wcap (the current update's W1 is the slot at column kp)
+    T*   dW1   = nullptr; // pending W1 panels, two regions of ldp x wcap
     T*   dY    = nullptr; // Y = H*Wp (kcap x wcap), correction of PHT under pending panels
-    int  wcap  = 0;       // columns of dW1
+    int  wcap  = 0;       // columns per region of dW1
     int  kp    = 0;       // pending columns (downdates not applied to P yet)
     int  defer_max = 0;   // > 0: keep up to this many pending columns across calls (cslam_ekf_set_deferred)
-    int  slot_col  = 0;   // first column of the last update's W1
     T*   dS    = nullptr;
     T*   dG    = nullptr;
     T*   dSub  = nullptr; // (3 + 64) x 64 compact block of PHT (see ekf_gather_kernel)
@@ -108,7 +133,6 @@ struct Ekf : EkfBase
     long long* dStamps = nullptr; // CSLAM_FACTOR_STAMPS=1: in-kernel phase stamps of the factor kernel (diagnostic)
     int   stamp_prints = 0;
     long long* dPsymStamps = nullptr; // CSLAM_PSYM_STAMPS=1
-    int*       dPredictDone = nullptr; // block-completion counter of the fused predict kernel
     int*       dTicket     = nullptr; // two tile-ticket counters used alternately by successive P-GEMM launches
     unsigned   launch_parity = 0;
     int        psym_nt = -1; // CSLAM_PSYM_NT: non-temporal P accesses in the P-GEMM (-1: by footprint)
@@ -138,6 +162,18 @@ struct Ekf : EkfBase
         {
             (void)hipStreamSynchronize(stream);
         }
+        if (stream_b && stream_b != stream)
+        {
+            (void)hipStreamSynchronize(stream_b);
+        }
+        if (ev_a2b)
+        {
+            (void)hipEventDestroy(ev_a2b);
+        }
+        if (ev_pgemm)
+        {
+            (void)hipEventDestroy(ev_pgemm);
+        }
         for (hipEvent_t e : ev_pool)
         {
             (void)hipEventDestroy(e);
@@ -151,6 +187,10 @@ struct Ekf : EkfBase
         }
         (void)hipFree(dX);
         (void)hipFree(dP);
+        (void)hipFree(dPv);
+        (void)hipFree(dWv);
+        (void)hipFree(dPoseDone);
+        (void)hipFree(dSign);
         free_workspace();
         (void)hipFree(dFlags);
         (void)hipFree(dHead);
@@ -158,7 +198,6 @@ struct Ekf : EkfBase
         (void)hipFree(dPsymStamps);
         (void)hipFree(dHwIds);
         (void)hipFree(dTicket);
-        (void)hipFree(dPredictDone);
         (void)hipFree(dPred);
         (void)hipFree(dAssoc);
         (void)hipFree(dAssocOut);
@@ -174,11 +213,17 @@ struct Ekf : EkfBase
         {
             (void)hipHostFree(hFlags);
         }
+        if (stream_b && stream_b != stream)
+        {
+            (void)hipStreamDestroy(stream_b);
+        }
         if (stream)
         {
             (void)hipStreamDestroy(stream);
         }
     }
+
+    T* wbase(int region) const { return dW1 + (size_t)region * wcap * ldp; }
 
     void free_workspace()
     {
@@ -210,7 +255,21 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        CSLAM_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (pipeline)
+        {
+            // the chain (A) outranks the P-GEMM (B): its small kernels must get in while the P-GEMM fills the chip
+            int lo = 0, hi = 0;
+            CSLAM_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+            CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream_b, hipStreamNonBlocking, lo));
+        }
+        else
+        {
+            CSLAM_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            stream_b = stream;
+        }
+        CSLAM_HIP_TRY(hipEventCreateWithFlags(&ev_a2b, hipEventDisableTiming));
+        CSLAM_HIP_TRY(hipEventCreateWithFlags(&ev_pgemm, hipEventDisableTiming));
         {
             hipDeviceProp_t prop;
             CSLAM_HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -221,6 +280,10 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMalloc(&dP, pbytes));
         CSLAM_HIP_TRY(hipMemsetAsync(dX, 0, (size_t)ldp * sizeof(T), stream));
         CSLAM_HIP_TRY(hipMemsetAsync(dP, 0, pbytes, stream));
+        CSLAM_HIP_TRY(hipMalloc(&dPv, (size_t)3 * ldp * sizeof(T)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPv, 0, (size_t)3 * ldp * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMalloc(&dPoseDone, 2 * sizeof(int)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPoseDone, 0, 2 * sizeof(int), stream));
         CSLAM_HIP_TRY(hipMalloc(&dFlags, 2 * sizeof(int)));
         CSLAM_HIP_TRY(hipMemsetAsync(dFlags, 0, 2 * sizeof(int), stream));
         CSLAM_HIP_TRY(hipHostMalloc(&hFlags, 2 * sizeof(int), hipHostMallocDefault));
@@ -241,8 +304,6 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipMalloc(&dPsymStamps, 64 * sizeof(long long)));
             CSLAM_HIP_TRY(hipMemsetAsync(dPsymStamps, 0, 64 * sizeof(long long), stream));
         }
-        CSLAM_HIP_TRY(hipMalloc(&dPredictDone, sizeof(int)));
-        CSLAM_HIP_TRY(hipMemsetAsync(dPredictDone, 0, sizeof(int), stream));
         CSLAM_HIP_TRY(hipMalloc(&dTicket, 2 * sizeof(int)));
         CSLAM_HIP_TRY(hipMemsetAsync(dTicket, 0, 2 * sizeof(int), stream));
         if (const char* sv = getenv("CSLAM_PSYM_NT"))
@@ -271,7 +332,7 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        rc = ensure_w(64);
+        rc = ensure_w(128);
         if (rc)
         {
             return rc;
@@ -313,6 +374,10 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMalloc(&dt_, (size_t)newk * sizeof(T)));
         CSLAM_HIP_TRY(hipMalloc(&dU, (size_t)newk * sizeof(T)));
         CSLAM_HIP_TRY(hipMemsetAsync(dPHT, 0, pan, stream));
+        (void)hipFree(dWv);
+        dWv = nullptr;
+        CSLAM_HIP_TRY(hipMalloc(&dWv, (size_t)3 * newk * sizeof(T)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dWv, 0, (size_t)3 * newk * sizeof(T), stream));
         kcap = newk;
         if (dY)
         {
@@ -326,7 +391,7 @@ struct Ekf : EkfBase
         return CSLAM_OK;
     }
 
-    // room for `cols` pending columns; flushes first when the buffer has to move
+    // room for `cols` pending columns per region; applies what is pending first when the buffer has to move
     int ensure_w(int cols)
     {
         cols = round_up(cols, 8);
@@ -335,24 +400,65 @@ struct Ekf : EkfBase
             return CSLAM_OK;
         }
         int rc = flush();
-        if (rc)
+        if (rc || (rc = sync_all()))
         {
             return rc;
         }
         int neww = round_up(std::max(cols, 2 * wcap), 8);
-        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         (void)hipFree(dW1);
         (void)hipFree(dY);
         dW1 = nullptr;
         dY  = nullptr;
-        CSLAM_HIP_TRY(hipMalloc(&dW1, (size_t)ldp * neww * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dW1, (size_t)2 * ldp * neww * sizeof(T)));
         CSLAM_HIP_TRY(hipMalloc(&dY, (size_t)std::max(kcap, 8) * neww * sizeof(T)));
-        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, (size_t)ldp * neww * sizeof(T), stream));
-        wcap = neww;
+        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, (size_t)2 * ldp * neww * sizeof(T), stream));
+        (void)hipFree(dSign);
+        dSign = nullptr;
+        CSLAM_HIP_TRY(hipMalloc(&dSign, ((size_t)2 * neww + 2) * sizeof(int)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dSign, 0, ((size_t)2 * neww + 2) * sizeof(int), stream));
+        hd_cols[0] = hd_cols[1] = 0;
+        wcap      = neww;
+        wcur      = 0;
+        last_slot = nullptr;
         return CSLAM_OK;
     }
 
-    // apply every pending panel to P in ONE P-GEMM with k = kp (slam.h:260 is linear in the panels)
+    int sync_all() override
+    {
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        if (stream_b != stream)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream_b));
+        }
+        inflight_mask = 0;
+        return CSLAM_OK;
+    }
+
+    // stream A waits until every P-GEMM launched so far (stream B) has completed: needed before anything reads or
+    // writes Ps, or writes a W1 region such a P-GEMM reads
+    int wait_pgemm()
+    {
+        if (inflight_mask != 0 && stream_b != stream)
+        {
+            CSLAM_HIP_TRY(hipStreamWaitEvent(stream, ev_pgemm, 0));
+        }
+        inflight_mask = 0;
+        return CSLAM_OK;
+    }
+
+    // before stream A writes into W1 region r
+    int own_region(int r)
+    {
+        return (inflight_mask & (1u << r)) ? wait_pgemm() : CSLAM_OK;
+    }
+
+    // launch the P-GEMM of every pending column (slam.h:260 is linear in the panels: ONE pass with k = kp) on stream B,
+    // ordered behind everything enqueued on stream A so far; the pending store moves on to the other region
     int flush()
     {
         if (kp == 0)
@@ -364,19 +470,72 @@ struct Ekf : EkfBase
         {
             return rc;
         }
+        T*        W   = wbase(wcur);
         const int kp8 = round_up(kp, 8);
         if (kp8 > kp) // the LDS-DMA P-GEMM reads W1 in blocks of 8 columns
         {
-            CSLAM_HIP_TRY(hipMemset2DAsync(dW1 + (size_t)kp * ldp, (size_t)ldp * sizeof(T), 0,
+            CSLAM_HIP_TRY(hipMemset2DAsync(W + (size_t)kp * ldp, (size_t)ldp * sizeof(T), 0,
                                            (size_t)round_up(n, kTile) * sizeof(T), (size_t)(kp8 - kp), stream));
         }
-        if ((rc = prof_begin(CSLAM_STAGE_DOWNDATE)) || (rc = launch_downdate(dW1, kp)) ||
-            (rc = prof_end(CSLAM_STAGE_DOWNDATE)))
+        if (stream_b != stream)
+        {
+            CSLAM_HIP_TRY(hipEventRecord(ev_a2b, stream));
+            CSLAM_HIP_TRY(hipStreamWaitEvent(stream_b, ev_a2b, 0));
+        }
+        if (hd_cols[wcur] > 0) // exceptional heading columns (S < 0) enter with the opposite sign: exits at once otherwise
+        {
+            if ((rc = launch_negcol_fix(W, kp, stream_b)))
+            {
+                return rc;
+            }
+        }
+        if ((rc = prof_begin(CSLAM_STAGE_DOWNDATE, stream_b)) || (rc = launch_downdate(W, kp, stream_b)) ||
+            (rc = prof_end(CSLAM_STAGE_DOWNDATE, stream_b)))
         {
             return rc;
         }
+        if (stream_b != stream)
+        {
+            CSLAM_HIP_TRY(hipEventRecord(ev_pgemm, stream_b));
+            inflight_mask |= 1u << wcur;
+        }
+        wcur ^= 1;
         kp = 0;
+        // the other region becomes the pending store: a still older P-GEMM may be reading it
+        if ((rc = own_region(wcur)))
+        {
+            return rc;
+        }
+        if (hd_cols[wcur] > 0) // its column signs belong to columns that have been applied
+        {
+            CSLAM_HIP_TRY(hipMemsetAsync(dSign + (size_t)wcur * wcap, 0, (size_t)wcap * sizeof(int), stream));
+            CSLAM_HIP_TRY(hipMemsetAsync(dSign + (size_t)2 * wcap + wcur, 0, sizeof(int), stream));
+            hd_cols[wcur] = 0;
+        }
         return CSLAM_OK;
+    }
+
+    int launch_negcol_fix(T* W, int kcols, hipStream_t st)
+    {
+        const int tiles = round_up(n, kTile) / kTile;
+        int       rc    = CSLAM_OK;
+        if (lower && (rc = ensure_tile_list(tiles)))
+        {
+            return rc;
+        }
+        const int nt = lower ? n_sym_tiles : tiles * tiles;
+        hipLaunchKernelGGL(ekf_negcol_fix_kernel<T>, dim3(std::min(nt, 2 * num_cus)), dim3(256), 0, st, dP, ldp, n, W, ldp,
+                           kcols, dSign + (size_t)wcur * wcap, dSign + (size_t)2 * wcap + wcur,
+                           lower ? dTiles : (const int2*)nullptr, nt, tiles);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    // everything applied and Ps quiescent as far as stream A is concerned
+    int flush_wait()
+    {
+        int rc = flush();
+        return rc ? rc : wait_pgemm();
     }
 
     size_t slot_bytes(int mc) const { return (size_t)mc * (2 * sizeof(T) + sizeof(int)); }
@@ -439,7 +598,7 @@ struct Ekf : EkfBase
         {
             return fail(CSLAM_ERR_BAD_ARG, "set_state: bad n=%d (cap %d) or ldp=%d", nn, ncap, ldph);
         }
-        int rc = use_device();
+        int rc = sync_all();
         if (rc)
         {
             return rc;
@@ -447,10 +606,16 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMemcpyAsync(dX, X, (size_t)nn * sizeof(T), hipMemcpyHostToDevice, stream));
         CSLAM_HIP_TRY(hipMemcpy2DAsync(dP, (size_t)ldp * sizeof(T), P, (size_t)ldph * sizeof(T), (size_t)nn * sizeof(T),
                                        (size_t)nn, hipMemcpyHostToDevice, stream));
+        // the pose stripe = columns 0..2 of P (contiguous in the column-major buffer)
+        CSLAM_HIP_TRY(hipMemcpyAsync(dPv, dP, (size_t)3 * ldp * sizeof(T), hipMemcpyDeviceToDevice, stream));
         // panels: rows beyond the new n must read as zero (the tuned gain kernel relies on it)
-        kp = 0; // a new state discards updates that were never applied
+        kp        = 0; // a new state discards updates that were never applied
+        wcur      = 0;
+        last_slot = nullptr;
+        hd_cols[0] = hd_cols[1] = 0;
+        CSLAM_HIP_TRY(hipMemsetAsync(dSign, 0, ((size_t)2 * wcap + 2) * sizeof(int), stream));
         CSLAM_HIP_TRY(hipMemsetAsync(dPHT, 0, (size_t)ldp * kcap * sizeof(T), stream));
-        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, (size_t)ldp * wcap * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dW1, 0, (size_t)2 * ldp * wcap * sizeof(T), stream));
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         n = nn;
         return CSLAM_OK;
@@ -467,7 +632,7 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        if (P && (rc = flush()))
+        if (P && (rc = flush_wait()))
         {
             return rc;
         }
@@ -483,6 +648,9 @@ struct Ekf : EkfBase
                 hipLaunchKernelGGL(ekf_mirror_upper_kernel<T>, dim3(g, g), dim3(256), 0, stream, dP, ldp, n);
                 CSLAM_HIP_TRY(hipGetLastError());
             }
+            // rows / columns 0..2 of the buffer come from the pose stripe
+            hipLaunchKernelGGL(ekf_patch_pose_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, stream, dP, dPv, ldp, n);
+            CSLAM_HIP_TRY(hipGetLastError());
             CSLAM_HIP_TRY(hipMemcpy2DAsync(P, (size_t)ldph * sizeof(T), dP, (size_t)ldp * sizeof(T),
                                            (size_t)n * sizeof(T), (size_t)n, hipMemcpyDeviceToHost, stream));
         }
@@ -510,12 +678,15 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        if ((rc = flush()))
+        if ((rc = flush_wait()))
         {
             return rc;
         }
         std::vector<T> diag((size_t)n);
         CSLAM_HIP_TRY(hipMemcpy2DAsync(diag.data(), sizeof(T), dP, ((size_t)ldp + 1) * sizeof(T), sizeof(T), (size_t)n,
+                                       hipMemcpyDeviceToHost, stream));
+        // the pose block lives in the stripe
+        CSLAM_HIP_TRY(hipMemcpy2DAsync(diag.data(), sizeof(T), dPv, ((size_t)ldp + 1) * sizeof(T), sizeof(T), (size_t)3,
                                        hipMemcpyDeviceToHost, stream));
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         double s = 0.0;
@@ -541,18 +712,19 @@ struct Ekf : EkfBase
         {
             return true;
         }
-        if (profiling == 3)
+        if (profiling == 3 || profiling == 4)
         {
             if (begin)
             {
-                prof_sampled = (prof_count++ % 16) == 0;
+                prof_sampled = (prof_count++ % (profiling == 3 ? 16u : 4u)) == 0;
             }
             return !prof_sampled;
         }
         return false;
     }
-    int prof_begin(int stage)
+    int prof_begin(int stage, hipStream_t st = nullptr)
     {
+        st = st ? st : stream;
         if (prof_skip(stage, true))
         {
             return CSLAM_OK;
@@ -568,22 +740,26 @@ struct Ekf : EkfBase
         }
         ev_stage.resize(ev_pool.size() / 2);
         ev_stage[ev_used / 2] = stage;
-        CSLAM_HIP_TRY(hipEventRecord(ev_pool[ev_used], stream));
+        CSLAM_HIP_TRY(hipEventRecord(ev_pool[ev_used], st));
         return CSLAM_OK;
     }
-    int prof_end(int stage)
+    int prof_end(int stage, hipStream_t st = nullptr)
     {
+        st = st ? st : stream;
         if (prof_skip(stage, false))
         {
             return CSLAM_OK;
         }
-        CSLAM_HIP_TRY(hipEventRecord(ev_pool[ev_used + 1], stream));
+        CSLAM_HIP_TRY(hipEventRecord(ev_pool[ev_used + 1], st));
         ev_used += 2;
         return CSLAM_OK;
     }
     int set_profiling(int on) override
     {
-        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        if (int rc = sync_all())
+        {
+            return rc;
+        }
         profiling  = on;
         ev_used    = 0;
         prof_count = 0;
@@ -595,7 +771,10 @@ struct Ekf : EkfBase
         {
             return fail(CSLAM_ERR_BAD_ARG, "get_stage_times: null");
         }
-        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        if (int rc = sync_all())
+        {
+            return rc;
+        }
         for (int s = 0; s < CSLAM_N_STAGES; s++)
         {
             ms[s]       = 0.0;
@@ -628,7 +807,7 @@ struct Ekf : EkfBase
             return CSLAM_OK;
         }
         int rc = use_device();
-        if (rc || (rc = flush()))
+        if (rc || (rc = flush_wait()))
         {
             return rc;
         }
@@ -659,7 +838,7 @@ struct Ekf : EkfBase
         }
         if (nf > 0)
         {
-            hipLaunchKernelGGL(ekf_assoc_feature_kernel<T>, dim3((nf + 255) / 256), dim3(256), 0, stream, dX, dP, ldp, n,
+            hipLaunchKernelGGL(ekf_assoc_feature_kernel<T>, dim3((nf + 255) / 256), dim3(256), 0, stream, dX, dP, dPv, ldp, n,
                                R[0], R[1], R[2], R[3], lower, dAssoc);
             CSLAM_HIP_TRY(hipGetLastError());
         }
@@ -672,11 +851,15 @@ struct Ekf : EkfBase
         return CSLAM_OK;
     }
 
-    // ---------------------------------------------------------------- predict (EKF.cpp:406-455)
-    // A predict() is accepted and held back: if the next call is a batch update on the fast path (f32, 16 < k <= 64,
-    // nothing pending), its gather / factor / gain kernels apply it on the fly and commit it (PredictArgs in
-    // ekf_kernels.hpp) and the predict launch disappears; every other consumer of X or P launches it first
-    // (resolve_predict).  CSLAM_FUSE_PREDICT=0 launches every predict at once.
+    // ---------------------------------------------------------------- predict (EKF.cpp:406-455) / heading (EKF.cpp:328-352)
+    // A predict() is accepted and held back until the next call shows what it can ride with:
+    //   observe_heading()  -> ONE ekf_pose_step_kernel launch does both (the reference's driver calls them back to back
+    //                         on every control step, test/main.cpp:165-168);
+    //   a batch update on the non-pipelined fast path (f32, 16 < k <= 64, nothing pending) -> its gather / factor / gain
+    //                         kernels apply the predict on the fly and commit it (PredictArgs in ekf_kernels.hpp);
+    //   anything else      -> launched on its own first (resolve_predict).  CSLAM_FUSE_PREDICT=0 launches every predict
+    //                         at once.
+    // Both only touch the pose stripe Pv and X, never Ps: they may run while a P-GEMM sweeps Ps on stream B.
     PredictArgs<T> pp{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
     T*             dPred = nullptr; // 16 scalars: factor kernel -> gain kernel (see FactorArgs::pred_out)
     bool           fuse_now = false; // the batch in flight consumes pp
@@ -700,7 +883,7 @@ struct Ekf : EkfBase
             w = (quirks & CSLAM_Q_PREDICT_NM4) ? (n - 4) : (n - 3);
         }
         pp = PredictArgs<T>{1, (T)v, (T)swa, Q[0], Q[1], Q[2], Q[3], (T)wb, (T)dt, std::max(w, 0)};
-        if (!fuse_predict || sizeof(T) != 4)
+        if (!fuse_predict)
         {
             return resolve_predict();
         }
@@ -709,30 +892,58 @@ struct Ekf : EkfBase
 
     void set_fuse_predict(int on) override { fuse_predict = on; }
 
+    // the pending predict and / or a heading observation in one launch
+    int pose_step(const HeadingArgs<T>& hd)
+    {
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        T* wcol = nullptr;
+        if (hd.valid)
+        {
+            if (n > 3)
+            {
+                // the rank-1 downdate -p p^T / S of the map block is one more pending column
+                if (kp + 1 > wcap && (rc = flush()))
+                {
+                    return rc;
+                }
+                if ((rc = own_region(wcur)))
+                {
+                    return rc;
+                }
+                wcol = wbase(wcur) + (size_t)kp * ldp;
+            }
+            else
+            {
+                wcol = dHead; // no map yet: the column would be all zero
+            }
+        }
+        const int      n_pad = round_up(n, kTile);
+        PredictArgs<T> p0    = pp;
+        pp.valid             = 0;
+        const bool col = hd.valid && n > 3;
+        hipLaunchKernelGGL(ekf_pose_step_kernel<T>, dim3(n_pad / 256 + ((n_pad % 256) ? 1 : 0)), dim3(256), 0, stream, dX, dPv,
+                           ldp, n, n_pad, p0, hd, wcol, col ? dSign + (size_t)wcur * wcap + kp : (int*)nullptr,
+                           dSign + (size_t)2 * wcap + wcur, dPoseDone);
+        CSLAM_HIP_TRY(hipGetLastError());
+        if (col)
+        {
+            kp += 1;
+            hd_cols[wcur] += 1;
+        }
+        return CSLAM_OK;
+    }
+
     int resolve_predict() override
     {
         if (!pp.valid)
         {
             return CSLAM_OK;
         }
-        int rc = use_device();
-        if (rc)
-        {
-            return rc;
-        }
-        pp.valid = 0;
-        if (kp > 0) // pose rows of the pending panels move with the pose (before anything changes X[2])
-        {
-            const int fix_last = (n > 3 && (quirks & CSLAM_Q_PREDICT_NM4)) ? 1 : 0;
-            hipLaunchKernelGGL(ekf_pending_predict_kernel<T>, dim3(1), dim3(256), 0, stream, dX, dP, ldp, n, pp.v, pp.swa,
-                               pp.dt, dW1, ldp, kp, fix_last);
-            CSLAM_HIP_TRY(hipGetLastError());
-        }
-        // stripe on many CUs + Pvv/pose by the last block to finish, one launch (w = 0: one block, Pvv/pose only)
-        hipLaunchKernelGGL(ekf_predict_stripe_kernel<T>, dim3(std::max(1, (pp.w + 255) / 256)), dim3(256), 0, stream, dX, dP,
-                           ldp, pp.v, pp.swa, pp.q00, pp.q10, pp.q01, pp.q11, pp.wb, pp.dt, pp.w, lower, dPredictDone);
-        CSLAM_HIP_TRY(hipGetLastError());
-        return CSLAM_OK;
+        return pose_step(HeadingArgs<T>{0, (T)0, (T)0});
     }
 
     // ---------------------------------------------------------------- update
@@ -767,7 +978,7 @@ struct Ekf : EkfBase
         solve_gain = false;
         g_from_gt  = false;
         a.pp       = fuse_now ? pp : PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
-        a.P3       = dP;
+        a.P3       = dPv; // the pose block lives in the stripe
         a.ldp3     = ldp;
         a.pred_out = dPred;
         a.lds_S    = 1;
@@ -887,38 +1098,43 @@ struct Ekf : EkfBase
         return CSLAM_OK;
     }
 
-    // W1 of this update goes to the pending slot starting at column slot_col
-    int launch_gain(int k)
+    // W1 of this update goes to `slot` (n_pad x k8 columns of the pending store); then the pose stripe takes its share
+    // of the downdate at once and the panel's pose rows are zeroed (ekf_pose_downdate_kernel)
+    int launch_gain(int k, T* slot)
     {
         const int n_pad = round_up(n, kTile);
-        T*        slot  = dW1 + (size_t)slot_col * ldp;
         if (launch_gain_fast(k, n_pad, slot))
         {
             CSLAM_HIP_TRY(hipGetLastError());
-            return CSLAM_OK;
-        }
-        if (k <= 64)
-        {
-            hipLaunchKernelGGL(ekf_gain_lds_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt,
-                               dt_, slot, dX);
         }
         else
         {
-            hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
-                               slot, dX);
+            if (k <= 64)
+            {
+                hipLaunchKernelGGL(ekf_gain_lds_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt,
+                                   dt_, slot, dX);
+            }
+            else
+            {
+                hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt,
+                                   dt_, slot, dX);
+            }
+            CSLAM_HIP_TRY(hipGetLastError());
         }
+        hipLaunchKernelGGL(ekf_pose_downdate_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, stream, slot, ldp, k,
+                           round_up(k, 8), n, dPv, ldp, dWv, dPoseDone + 1);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
 
-    int  launch_downdate(const T* W, int k);
+    int  launch_downdate(const T* W, int k, hipStream_t st);
     bool launch_factor_blocked(const FactorArgs<T>& a, int k); // f32, 32 < k <= 64
-    bool launch_corr_fast(int k);                               // PHT -= Wp*Y^T on MFMA (f32)
+    bool launch_corr_fast(int k, const T* Wp, int kc);          // PHT -= Wp*Y^T on MFMA (f32)
     int  ensure_tile_list(int tiles);
     bool launch_gain_fast(int k, int n_pad, T* slot); // MFMA gain (f32, k <= 128 where du is available)
 
     // one batch of m observations with device-resident Z / idf (slam.h:235-266 via EKF.cpp:93-129).
-    // keep_pending: leave this update's P-GEMM to a later flush() (sequential mode, deferred mode).
+    // keep_pending: never start this update's (or any pending) P-GEMM inside the call (sequential mode).
     int batch_on_device(const T* dZ, const int* dIdf, int m, const T* R, bool keep_pending)
     {
         const int k  = 2 * m;
@@ -927,9 +1143,9 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        // a pending predict() rides along when this batch takes the fast path with nothing else pending
-        fuse_now = pp.valid && sizeof(T) == 4 && !keep_pending && kp == 0 && k > 16 && k <= 64 && tune_factor == 0 &&
-                   tune_gain == 0;
+        // a pending predict() rides along when this batch takes the (non-pipelined) fast path with nothing else pending
+        fuse_now = pp.valid && sizeof(T) == 4 && !pipeline && !keep_pending && kp == 0 && k > 16 && k <= 64 &&
+                   tune_factor == 0 && tune_gain == 0;
         if (pp.valid && !fuse_now && (rc = resolve_predict()))
         {
             return rc;
@@ -938,19 +1154,29 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipMalloc(&dPred, 16 * sizeof(T)));
         }
-        if (kp + k > std::max(wcap, 0) || (kp > 0 && kp + k > std::max(defer_max, kp_call_limit)))
+        if ((rc = ensure_w(std::max(k, kp_call_limit)))) // (may flush and move the store)
         {
-            if ((rc = flush()))
+            return rc;
+        }
+        // Pipelined: the pending columns' P-GEMM starts right behind this update's gather and runs under its chain.
+        // It is held back while an explicit deferral window (cslam_ekf_set_deferred) still has room for this panel.
+        const bool overlap = pipeline && !keep_pending && kp > 0 && (defer_max == 0 || kp + k > defer_max);
+        // pending columns stay pending through this update while they fit the window: the explicit deferral window, the
+        // sequential call's own columns, else the store (e.g. heading columns in immediate mode: applied together with
+        // this update's panel by the flush below)
+        const int window = std::min(wcap, defer_max > 0 ? defer_max : (kp_call_limit > 0 ? kp_call_limit : wcap));
+        if (!overlap && kp > 0 && kp + k > window)
+        {
+            if ((rc = flush())) // no room to keep them pending: apply them first
             {
                 return rc;
             }
         }
-        if ((rc = ensure_w(kp + k)))
+        if ((rc = wait_pgemm())) // Ps must be quiescent for the gather
         {
             return rc;
         }
-        last_k   = k;
-        slot_col = kp;
+        last_k = k;
         if ((rc = prof_begin(CSLAM_STAGE_GATHER)))
         {
             return rc;
@@ -959,24 +1185,40 @@ struct Ekf : EkfBase
         // the compact H-rows block for the MFMA factor kernel (f32, 16 < k <= 64, no pending panels to correct)
         sub_valid = (sizeof(T) == 4 && k > 16 && k <= 64 && kp == 0 && tune_factor == 0 && dSub != nullptr);
         PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
-        hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, ldp, n, dZ, dIdf, m, dPHT, ldp, lower,
-                           sub_valid ? dSub : nullptr, fuse_now ? pp : pnone, fuse_now ? dPred : (T*)nullptr);
+        hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, dPv, ldp, n, dZ, dIdf, m, dPHT, ldp,
+                           lower, sub_valid ? dSub : nullptr, fuse_now ? pp : pnone, fuse_now ? dPred : (T*)nullptr);
         CSLAM_HIP_TRY(hipGetLastError());
-        if (kp > 0) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T
+        // the panels this update's P*H^T must be corrected with, and where its own W1 goes
+        const T*  Wc        = wbase(wcur);
+        const int kc        = kp;
+        const int rc_region = wcur;
+        if (overlap)
         {
-            hipLaunchKernelGGL(ekf_pending_y_kernel<T>, dim3(m, (kp + 255) / 256), dim3(256), 0, stream, dX, n, dZ, dIdf, m,
-                               dW1, ldp, kp, dY);
-            CSLAM_HIP_TRY(hipGetLastError());
-            if (!launch_corr_fast(k))
+            if ((rc = flush())) // P-GEMM of the pending columns on stream B, behind the gather; store -> other region
             {
-                hipLaunchKernelGGL(ekf_pending_corr_kernel<T>, ggrid, dim3(256), 0, stream, n, m, dW1, ldp, kp, dY, dPHT,
+                return rc;
+            }
+        }
+        T* slot = wbase(wcur) + (size_t)kp * ldp;
+        if ((rc = own_region(wcur)))
+        {
+            return rc;
+        }
+        if (kc > 0) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T (their pose rows are zero)
+        {
+            hipLaunchKernelGGL(ekf_pending_y_kernel<T>, dim3(m, (kc + 255) / 256), dim3(256), 0, stream, dX, n, dZ, dIdf, m,
+                               Wc, ldp, kc, dY, hd_cols[rc_region] > 0 ? dSign + (size_t)rc_region * wcap : (const int*)nullptr);
+            CSLAM_HIP_TRY(hipGetLastError());
+            if (!launch_corr_fast(k, Wc, kc))
+            {
+                hipLaunchKernelGGL(ekf_pending_corr_kernel<T>, ggrid, dim3(256), 0, stream, n, m, Wc, ldp, kc, dY, dPHT,
                                    ldp);
             }
             CSLAM_HIP_TRY(hipGetLastError());
         }
         if ((rc = prof_end(CSLAM_STAGE_GATHER)) || (rc = prof_begin(CSLAM_STAGE_FACTOR)) ||
             (rc = launch_factor(dZ, dIdf, m, R)) || (rc = prof_end(CSLAM_STAGE_FACTOR)) ||
-            (rc = prof_begin(CSLAM_STAGE_GAIN)) || (rc = launch_gain(k)) || (rc = prof_end(CSLAM_STAGE_GAIN)))
+            (rc = prof_begin(CSLAM_STAGE_GAIN)) || (rc = launch_gain(k, slot)) || (rc = prof_end(CSLAM_STAGE_GAIN)))
         {
             return rc;
         }
@@ -985,8 +1227,9 @@ struct Ekf : EkfBase
             pp.valid = 0;
             fuse_now = false;
         }
+        last_slot = slot;
         kp += k;
-        const bool deferring = keep_pending || defer_max > 0;
+        const bool deferring = keep_pending || pipeline || defer_max > 0;
         if (!deferring && (rc = flush()))
         {
             return rc;
@@ -1000,9 +1243,9 @@ struct Ekf : EkfBase
                 return eigen_fallback(k, deferring);
             }
         }
-        // deferred mode: once the pending store is full, apply it now rather than at the start of the next update --
-        // the predict in between then has no pending panels to transform
-        if (!keep_pending && defer_max > 0 && kp >= defer_max && (rc = flush()))
+        // explicit deferral without pipelining: once the window is full, apply it now rather than at the start of
+        // the next update
+        if (!pipeline && !keep_pending && defer_max > 0 && kp >= defer_max && (rc = flush()))
         {
             return rc;
         }
@@ -1047,8 +1290,13 @@ struct Ekf : EkfBase
         }
         CSLAM_HIP_TRY(hipMemcpyAsync(dU, u.data(), u.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         int rc;
+        if ((rc = own_region(wcur)))
+        {
+            return rc;
+        }
         // the zero G made this update's W1 slot zero (a no-op wherever it was or will be applied): rewrite it
-        if ((rc = launch_gain(k)))
+        // (the gain kernel's pose downdate runs again on the new panel: the first one subtracted zeros)
+        if ((rc = launch_gain(k, last_slot)))
         {
             return rc;
         }
@@ -1057,10 +1305,10 @@ struct Ekf : EkfBase
             const int k8 = round_up(k, 8);
             if (k8 > k)
             {
-                CSLAM_HIP_TRY(hipMemset2DAsync(dW1 + (size_t)(slot_col + k) * ldp, (size_t)ldp * sizeof(T), 0,
+                CSLAM_HIP_TRY(hipMemset2DAsync(last_slot + (size_t)k * ldp, (size_t)ldp * sizeof(T), 0,
                                                (size_t)round_up(n, kTile) * sizeof(T), (size_t)(k8 - k), stream));
             }
-            if ((rc = launch_downdate(dW1 + (size_t)slot_col * ldp, k)))
+            if ((rc = launch_downdate(last_slot, k, stream)))
             {
                 return rc;
             }
@@ -1111,11 +1359,18 @@ struct Ekf : EkfBase
             return rc;
         }
         // EKF.cpp:457-479: m successive rank-2 updates, relinearised on the updated state each time.  Their m
-        // rank-2 downdates are deferred and applied by ONE P-GEMM with k = 2m at the end of the call: each
-        // observation reads the columns it needs as Ps[:,c] - Wp*Wp[c,:]^T.
-        if (seq_defer && (rc = ensure_w(kp + 2 * m)))
+        // rank-2 downdates stay pending and are applied by ONE P-GEMM with k = 2m: each observation reads the columns
+        // it needs as Ps[:,c] - Wp*Wp[c,:]^T.
+        if (seq_defer)
         {
-            return rc;
+            if ((rc = ensure_w(2 * m)))
+            {
+                return rc;
+            }
+            if (kp + 2 * m > wcap && (rc = flush()))
+            {
+                return rc;
+            }
         }
         kp_call_limit = seq_defer ? kp + 2 * m : 0;
         for (int i = 0; i < m; i++)
@@ -1127,7 +1382,7 @@ struct Ekf : EkfBase
             }
         }
         kp_call_limit = 0;
-        if (defer_max == 0 && (rc = flush()))
+        if (!pipeline && defer_max == 0 && (rc = flush()))
         {
             return rc;
         }
@@ -1150,17 +1405,17 @@ struct Ekf : EkfBase
         {
             return rc;
         }
+        if (q > 0 && (rc = wait_pgemm())) // the new rows / columns of Ps are written here: no P-GEMM may be sweeping it
+        {
+            return rc;
+        }
         const T* Z = static_cast<const T*>(Zv);
         const T* R = static_cast<const T*>(Rv);
         for (int i = 0; i < q; i++)
         {
-            if (kp > 0)
-            {
-                hipLaunchKernelGGL(ekf_pending_augment_kernel<T>, dim3(1), dim3(256), 0, stream, dX, n, Z[2 * i],
-                                   Z[2 * i + 1], dW1, ldp, kp);
-                CSLAM_HIP_TRY(hipGetLastError());
-            }
-            hipLaunchKernelGGL(ekf_augment_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, Z[2 * i],
+            // (pending panels: their rows for the new feature are zero, which is right -- the kernel writes values of
+            // the true P, built from the pose stripe)
+            hipLaunchKernelGGL(ekf_augment_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, dPv, ldp, n, Z[2 * i],
                                Z[2 * i + 1], R[0], R[1], R[2], R[3], lower);
             CSLAM_HIP_TRY(hipGetLastError());
             n += 2;
@@ -1173,31 +1428,11 @@ struct Ekf : EkfBase
     {
         if (!use)
         {
-            return CSLAM_OK;
-        }
-        int rc = use_device();
-        if (rc)
-        {
-            return rc;
-        }
-        if ((rc = flush())) // the rank-structured Joseph update reads and rewrites all of P
-        {
-            return rc;
+            return CSLAM_OK; // EKF.cpp:332-335 (a pending predict stays pending)
         }
         // float sigmaPhi = 0.01F * pi / 180.0F; R = pow(sigmaPhi, 2)
         T sigma = (T)(((double)0.01f * kPi) / 180.0);
-        T R     = sigma * sigma;
-        T* w    = dHead;
-        T* cp2  = dHead + ldp;
-        T* rrow = dHead + 2 * (size_t)ldp;
-        T* scal = dHead + 3 * (size_t)ldp;
-        hipLaunchKernelGGL(ekf_heading_prep_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, ldp, n, (T)phi, R, w, cp2,
-                           rrow, scal, lower);
-        CSLAM_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(ekf_heading_apply_kernel<T>, dim3((n + 255) / 256, (n + 15) / 16), dim3(256), 0, stream, dP,
-                           ldp, n, w, cp2, rrow, scal, (T)FLT_MIN, lower);
-        CSLAM_HIP_TRY(hipGetLastError());
-        return CSLAM_OK;
+        return pose_step(HeadingArgs<T>{1, (T)phi, sigma * sigma}); // with the pending predict, if any, in the same launch
     }
 
     int factor_status(int* flags, int clear) override
@@ -1244,7 +1479,7 @@ struct Ekf : EkfBase
             return rc;
         }
         defer_max = max_cols;
-        return max_cols > 0 ? ensure_w(max_cols) : CSLAM_OK;
+        return max_cols > 0 ? ensure_w(max_cols + 64) : CSLAM_OK;
     }
 
     int do_flush() override { return flush(); }
@@ -1256,7 +1491,7 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        const int k = last_k;
+        const int k = last_slot ? last_k : 0;
         if (kout)
         {
             *kout = k;
@@ -1272,8 +1507,16 @@ struct Ekf : EkfBase
         }
         if (W1)
         {
-            CSLAM_HIP_TRY(hipMemcpy2DAsync(W1, (size_t)n * sizeof(T), dW1 + (size_t)slot_col * ldp, (size_t)ldp * sizeof(T),
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(W1, (size_t)n * sizeof(T), last_slot, (size_t)ldp * sizeof(T),
                                            (size_t)n * sizeof(T), (size_t)k, hipMemcpyDeviceToHost, stream));
+            // its pose rows were zeroed in the store after the pose stripe took its share (ekf_pose_downdate_kernel
+            // saved them): rows 0..2 <- dWv (3 x k, row c at c*k)
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(W1, (size_t)n * sizeof(T), dWv, sizeof(T), sizeof(T), (size_t)k,
+                                           hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(static_cast<T*>(W1) + 1, (size_t)n * sizeof(T), dWv + k, sizeof(T), sizeof(T),
+                                           (size_t)k, hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipMemcpy2DAsync(static_cast<T*>(W1) + 2, (size_t)n * sizeof(T), dWv + 2 * k, sizeof(T), sizeof(T),
+                                           (size_t)k, hipMemcpyDeviceToHost, stream));
         }
         if (S)
         {
@@ -1360,7 +1603,10 @@ int Ekf<T>::ensure_tile_list(int tiles)
             h.push_back(make_int2(ti, tj));
         }
     }
-    CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+    if (int rc = sync_all()) // (a P-GEMM in flight still reads the old list)
+    {
+        return rc;
+    }
     (void)hipFree(dTiles);
     dTiles = nullptr;
     CSLAM_HIP_TRY(hipMalloc(&dTiles, h.size() * sizeof(int2)));
@@ -1371,7 +1617,7 @@ int Ekf<T>::ensure_tile_list(int tiles)
 }
 
 template <>
-int Ekf<float>::launch_downdate(const float* W, int k)
+int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
 {
     const int  tiles = round_up(n, kTile) / kTile;
     const dim3 grid(tiles * tiles), block(256);
@@ -1392,7 +1638,10 @@ int Ekf<float>::launch_downdate(const float* W, int k)
         {
             return rc;
         }
-        const int G = std::min(n_sym_tiles, 2 * num_cus);
+        // Persistent grid: two workgroups per CU, minus `pgemm_spare` -- a few CUs keep one workgroup (64 of 160 KB LDS)
+        // so that the one-workgroup factor kernel of the NEXT update (53 KB LDS, stream A) finds room while this P-GEMM
+        // fills the chip (pipelined mode).
+        const int G = std::min(n_sym_tiles, std::max(1, 2 * num_cus - (pipeline ? pgemm_spare : 0)));
         if (k8 <= 128 && lower && tune_downdate == 0 && ldp < 32768)
         {
             // every memory operation interleaved with the MFMA loop; two (k <= 64) or four (k <= 128) chunks of 32
@@ -1528,22 +1777,21 @@ bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot)
         return false; // du is produced by the tuned factor kernels only
     }
     hipLaunchKernelGGL((ekf_panel_mfma_f32<false, true>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n,
-                       k, k, dGt, k, dU, slot, ldp, dX, fuse_now ? (const float*)dPred : (const float*)nullptr, pp.w, dP, ldp,
-                       lower);
+                       k, k, dGt, k, dU, slot, ldp, dX, fuse_now ? (const float*)dPred : (const float*)nullptr, pp.w, dPv, ldp);
     return true;
 }
 
 template <>
-bool Ekf<float>::launch_corr_fast(int k)
+bool Ekf<float>::launch_corr_fast(int k, const float* Wp, int kc)
 {
     const int n_pad = round_up(n, kTile);
-    hipLaunchKernelGGL((ekf_panel_mfma_f32<true, false>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dW1, ldp, n,
-                       kp, k, dY, k, nullptr, dPHT, ldp, nullptr);
+    hipLaunchKernelGGL((ekf_panel_mfma_f32<true, false>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, Wp, ldp, n,
+                       kc, k, dY, k, nullptr, dPHT, ldp, nullptr);
     return true;
 }
 
 template <>
-bool Ekf<double>::launch_corr_fast(int)
+bool Ekf<double>::launch_corr_fast(int, const double*, int)
 {
     return false;
 }
@@ -1572,7 +1820,7 @@ bool Ekf<double>::launch_gain_fast(int, int, double*)
 }
 
 template <>
-int Ekf<double>::launch_downdate(const double* W, int k)
+int Ekf<double>::launch_downdate(const double* W, int k, hipStream_t stream)
 {
     const int tiles_r = round_up(n, kTile) / kTile;
     const int tiles_c = round_up(n, kTile) / 64;
@@ -1697,6 +1945,16 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
             b->lower = 1;
         }
     }
+    // two-stream pipelining (see the top of this file): default for the f32 block-lower engine
+    b->pipeline = (dtype == CSLAM_F32 && b->lower) ? 1 : 0;
+    if (const char* pv = getenv("CSLAM_PIPELINE"))
+    {
+        b->pipeline = atoi(pv) ? 1 : 0;
+    }
+    if (const char* sp = getenv("CSLAM_PGEMM_SPARE"))
+    {
+        b->pgemm_spare = std::max(0, atoi(sp));
+    }
     int rc    = b->init();
     if (rc)
     {
@@ -1789,9 +2047,7 @@ int cslam_ekf_synchronize(cslam_ekf_t h)
     {
         return rc;
     }
-    CSLAM_HIP_TRY(hipSetDevice(B(h)->device));
-    CSLAM_HIP_TRY(hipStreamSynchronize(B(h)->stream));
-    return CSLAM_OK;
+    return B(h)->sync_all();
 }
 
 int cslam_ekf_factor_status(cslam_ekf_t h, int* flags, int clear)
@@ -1842,11 +2098,86 @@ int cslam_ekf_associate(cslam_ekf_t h, const void* Z, int m, const void* R, doub
 int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading)
 {
     CSLAM_NEED(h);
-    if (int rc = B(h)->resolve_predict())
+    return B(h)->observe_heading(phi, use_heading); // (a pending predict rides in the same launch)
+}
+
+int cslam_ekf_get_streams(cslam_ekf_t h, void** chain_stream, void** pgemm_stream)
+{
+    CSLAM_NEED(h);
+    if (chain_stream)
     {
-        return rc;
+        *chain_stream = reinterpret_cast<void*>(B(h)->stream);
     }
-    return B(h)->observe_heading(phi, use_heading);
+    if (pgemm_stream)
+    {
+        *pgemm_stream = reinterpret_cast<void*>(B(h)->stream_b);
+    }
+    return CSLAM_OK;
+}
+
+int cslam_ekf_run_many(cslam_ekf_t* handles, int count, int steps, const double* v, const double* swa, const void* Q,
+                       double wb, double dt, const void* const* dZ, const int* const* d_idf, int m, const void* R,
+                       int batch)
+{
+    if (!handles || count < 0 || steps < 0 || m < 0 || !R || !Q || (steps > 0 && (!v || !swa)) || (m > 0 && (!dZ || !d_idf)))
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "run_many: bad arguments");
+    }
+    for (int i = 0; i < count; i++)
+    {
+        if (!handles[i] || (m > 0 && (!dZ[i] || !d_idf[i])))
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "run_many: null handle or input for instance %d", i);
+        }
+    }
+    // one host thread per instance: every instance is an independent filter on its own stream pair, so the launches of
+    // different instances are issued concurrently and their kernels interleave on the device (no ordering between them)
+    std::vector<int>         rcs((size_t)count, CSLAM_OK);
+    std::vector<std::string> msgs((size_t)count);
+    auto                     body = [&](int i) {
+        EkfBase*     e     = B(handles[i]);
+        const size_t esz   = (e->dtype == CSLAM_F32) ? sizeof(float) : sizeof(double);
+        const char*  zbase = m > 0 ? static_cast<const char*>(dZ[i]) : nullptr;
+        for (int t = 0; t < steps; t++)
+        {
+            int rc = e->predict(v[t], swa[t], Q, wb, dt);
+            if (!rc && m > 0)
+            {
+                rc = e->update(zbase + (size_t)t * 2 * m * esz, m, R, d_idf[i] + (size_t)t * m, batch, true);
+            }
+            if (rc)
+            {
+                rcs[(size_t)i]  = rc;
+                msgs[(size_t)i] = last_error_buf(); // (thread-local: carried back to the caller's thread below)
+                return;
+            }
+        }
+    };
+    if (count == 1)
+    {
+        body(0);
+    }
+    else
+    {
+        std::vector<std::thread> th;
+        th.reserve((size_t)count);
+        for (int i = 0; i < count; i++)
+        {
+            th.emplace_back(body, i);
+        }
+        for (auto& t : th)
+        {
+            t.join();
+        }
+    }
+    for (int i = 0; i < count; i++)
+    {
+        if (rcs[(size_t)i])
+        {
+            return fail(rcs[(size_t)i], "run_many: instance %d: %s", i, msgs[(size_t)i].c_str());
+        }
+    }
+    return CSLAM_OK;
 }
 
 int cslam_ekf_set_profiling(cslam_ekf_t h, int on)

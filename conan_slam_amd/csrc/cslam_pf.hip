@@ -6,6 +6,8 @@
 // pack / unpack of particle records, local gather) so that a multi-GPU driver can put its collectives
 // between them (conan_slam_amd/pf.py does that with torch.distributed over RCCL).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types only: the library itself is bound with dlopen (see Rccl below)
 
 #include <cstring>
 #include <new>
@@ -18,6 +20,83 @@ using namespace cslam;
 
 namespace
 {
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, bound at run time.  One process must hold ONE copy of librccl (PyTorch wheels bundle their own, as they do
+// libamdhip64): dlopen by SONAME returns the copy the process already has, else the system one.
+// ------------------------------------------------------------------------------------------------
+struct Rccl
+{
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*)                                                            = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int)                                     = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t)                                                               = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)        = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)               = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)                     = nullptr;
+    ncclResult_t (*GroupStart)()                                                                          = nullptr;
+    ncclResult_t (*GroupEnd)()                                                                            = nullptr;
+    const char* (*GetErrorString)(ncclResult_t)                                                           = nullptr;
+};
+
+inline Rccl* rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (!tried)
+    {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib)
+            {
+                break;
+            }
+        }
+        if (r.lib)
+        {
+#define CSLAM_RCCL_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym))
+            CSLAM_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+            CSLAM_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+            CSLAM_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+            CSLAM_RCCL_SYM(AllReduce, "ncclAllReduce");
+            CSLAM_RCCL_SYM(AllGather, "ncclAllGather");
+            CSLAM_RCCL_SYM(Send, "ncclSend");
+            CSLAM_RCCL_SYM(Recv, "ncclRecv");
+            CSLAM_RCCL_SYM(GroupStart, "ncclGroupStart");
+            CSLAM_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+            CSLAM_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef CSLAM_RCCL_SYM
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather || !r.Send || !r.Recv ||
+                !r.GroupStart || !r.GroupEnd)
+            {
+                r.lib = nullptr;
+            }
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+
+#define CSLAM_RCCL_TRY(expr)                                                                                         \
+    do                                                                                                               \
+    {                                                                                                                \
+        ncclResult_t r__ = (expr);                                                                                   \
+        if (r__ != ncclSuccess)                                                                                      \
+        {                                                                                                            \
+            return ::cslam::fail(CSLAM_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                                      \
+                                 rccl()->GetErrorString ? rccl()->GetErrorString(r__) : "rccl error", __FILE__, __LINE__); \
+        }                                                                                                            \
+    } while (0)
+
+struct Comm
+{
+    ncclComm_t comm   = nullptr;
+    int        rank   = 0;
+    int        world  = 1;
+    int        device = 0;
+};
 
 struct PfBase
 {
@@ -47,6 +126,7 @@ struct PfBase
     virtual int unpack(const int* idx, int count, const void* drec)                           = 0;
     virtual int gather_local(const int* keep, double w_new)                                   = 0;
     virtual int resample_local(const void* select, double n_eff, int status, double* neff, int* did) = 0;
+    virtual int resample_sharded(Comm* c, const void* select, double n_eff, int status, double* neff, int* did) = 0;
     virtual int get_particle(int i, void* w, void* Xv, void* Pv, void* XF, void* PF)          = 0;
     virtual int set_particle(int i, const void* w, const void* Xv, const void* Pv, const void* XF, const void* PF,
                              int nf)                                                          = 0;
@@ -84,6 +164,18 @@ struct Pf : PfBase
             (void)hipStreamSynchronize(stream);
         }
         (void)hipFree(dW);
+        (void)hipFree(dSumsG);
+        (void)hipFree(dWall);
+        (void)hipFree(dSelG);
+        (void)hipFree(dKeepG);
+        (void)hipFree(dSendIdx);
+        (void)hipFree(dCounts);
+        (void)hipFree(dSendBuf);
+        (void)hipFree(dRecvBuf);
+        if (hCounts)
+        {
+            (void)hipHostFree(hCounts);
+        }
         (void)hipFree(dSel);
         (void)hipFree(dCum);
         (void)hipFree(dKeep);
@@ -636,6 +728,175 @@ struct Pf : PfBase
         return CSLAM_OK;
     }
 
+    // PF.cpp:473-500 over a particle set sharded across ranks (one rank per GPU): see cslam_pf_resample_sharded in
+    // include/cslam.h.  Everything is ordered on the handle's stream; the host reads back the two global sums (the
+    // decision must be the same on every rank and drives which collectives run) and, when it resamples, the
+    // 2 x world record counts of the exchange.
+    double* dSumsG   = nullptr;
+    T*      dWall    = nullptr;
+    T*      dSelG    = nullptr;
+    int*    dKeepG   = nullptr;
+    int*    dSendIdx = nullptr;
+    int*    dCounts  = nullptr;
+    int*    hCounts  = nullptr;
+    T*      dSendBuf = nullptr;
+    T*      dRecvBuf = nullptr;
+    int     sh_world = 0;
+    int     sh_nf    = -1;
+    int resample_sharded(Comm* c, const void* select, double n_eff, int status, double* neff, int* did) override
+    {
+        Rccl* R = rccl();
+        if (!R)
+        {
+            return fail(CSLAM_ERR_HIP, "pf_resample_sharded: librccl could not be loaded");
+        }
+        if (!c || !select)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_resample_sharded: null communicator or select");
+        }
+        const int world = c->world, rank = c->rank, L = np, N = np * world;
+        if (N > kPfPlanMax)
+        {
+            return fail(CSLAM_ERR_CAPACITY, "pf_resample_sharded: %d particles in total (limit %d)", N, kPfPlanMax);
+        }
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const ncclDataType_t dt = (sizeof(T) == 4) ? ncclFloat : ncclDouble;
+        if (sh_world != world)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(dSumsG);
+            (void)hipFree(dWall);
+            (void)hipFree(dSelG);
+            (void)hipFree(dKeepG);
+            (void)hipFree(dSendIdx);
+            (void)hipFree(dCounts);
+            if (hCounts)
+            {
+                (void)hipHostFree(hCounts);
+            }
+            CSLAM_HIP_TRY(hipMalloc(&dSumsG, 2 * sizeof(double)));
+            CSLAM_HIP_TRY(hipMalloc(&dWall, (size_t)N * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dSelG, (size_t)N * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dKeepG, (size_t)N * sizeof(int)));
+            CSLAM_HIP_TRY(hipMalloc(&dSendIdx, (size_t)N * sizeof(int)));
+            CSLAM_HIP_TRY(hipMalloc(&dCounts, (size_t)2 * world * sizeof(int)));
+            CSLAM_HIP_TRY(hipHostMalloc(&hCounts, ((size_t)2 * world + 4) * sizeof(double), hipHostMallocDefault));
+            sh_world = world;
+            sh_nf    = -1;
+        }
+        // 1. global weight sums
+        hipLaunchKernelGGL(pf_weight_sums_kernel<T>, dim3(1), dim3(256), 0, stream, dW, np, dSums);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_RCCL_TRY(R->AllReduce(dSums, dSumsG, 2, ncclDouble, ncclSum, c->comm, stream));
+        double* hs = reinterpret_cast<double*>(hCounts); // (pinned; the counts use it later)
+        CSLAM_HIP_TRY(hipMemcpyAsync(hs, dSumsG, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        stage_inflight = 0;
+        const double ws = hs[0], ws2 = hs[1];
+        // 2. w /= ws (PF.cpp:482-487), Neff = 1 / sum (w/ws)^2 (PF.cpp:549-554), the decision (PF.cpp:490)
+        hipLaunchKernelGGL(pf_scale_weights_kernel<T>, dim3((np + 255) / 256), dim3(256), 0, stream, dW, np, (T)(1.0 / ws), 0);
+        CSLAM_HIP_TRY(hipGetLastError());
+        const double ne = (ws2 > 0.0) ? (ws * ws) / ws2 : 0.0;
+        const bool   go = (ne < n_eff) && status;
+        if (neff)
+        {
+            *neff = ne;
+        }
+        if (did)
+        {
+            *did = go ? 1 : 0;
+        }
+        if (!go)
+        {
+            return CSLAM_OK;
+        }
+        // 3. every rank plans the same keep[] from the gathered weights and the shared strata
+        CSLAM_RCCL_TRY(R->AllGather(dW, dWall, (size_t)L, dt, c->comm, stream));
+        char* slot = nullptr;
+        if ((rc = stage_slot_for((size_t)N * sizeof(T), &slot)))
+        {
+            return rc;
+        }
+        std::memcpy(slot, select, (size_t)N * sizeof(T));
+        CSLAM_HIP_TRY(hipMemcpyAsync(dSelG, slot, (size_t)N * sizeof(T), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(pf_keep_kernel<T>, dim3(1), dim3(256), 0, stream, dWall, N, dSelG, dKeepG);
+        CSLAM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(pf_exchange_plan_kernel<0>, dim3(1), dim3(256), 0, stream, dKeepG, N, L, rank, world, dSendIdx,
+                           dCounts);
+        CSLAM_HIP_TRY(hipGetLastError());
+        int* hc = reinterpret_cast<int*>(hCounts) + 8;
+        CSLAM_HIP_TRY(hipMemcpyAsync(hc, dCounts, (size_t)2 * world * sizeof(int), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        stage_inflight = 0;
+        int n_send = 0, n_recv = 0;
+        for (int r = 0; r < world; r++)
+        {
+            n_send += hc[r];
+            n_recv += hc[world + r];
+        }
+        if (n_recv != L)
+        {
+            return fail(CSLAM_ERR_HIP, "pf_resample_sharded: exchange plan fills %d of %d slots", n_recv, L);
+        }
+        const size_t rec = (size_t)(13 + 6 * nf);
+        if (sh_nf != nf)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(dSendBuf);
+            (void)hipFree(dRecvBuf);
+            dSendBuf = dRecvBuf = nullptr;
+            CSLAM_HIP_TRY(hipMalloc(&dSendBuf, (size_t)N * rec * sizeof(T))); // worst case: every slot keeps a particle of this rank
+            CSLAM_HIP_TRY(hipMalloc(&dRecvBuf, (size_t)L * rec * sizeof(T)));
+            sh_nf = nf;
+        }
+        // 4. records out of the store (before any slot is overwritten), exchange, records into the slots in order
+        if (n_send > 0)
+        {
+            hipLaunchKernelGGL(pf_pack_kernel<T>, dim3(n_send), dim3(256), 0, stream, store(), dSendIdx, n_send, dSendBuf);
+            CSLAM_HIP_TRY(hipGetLastError());
+        }
+        CSLAM_RCCL_TRY(R->GroupStart());
+        size_t soff = 0, roff = 0;
+        for (int r = 0; r < world; r++)
+        {
+            const size_t sc = (size_t)hc[r], rcv = (size_t)hc[world + r];
+            if (r == rank)
+            {
+                if (sc != rcv)
+                {
+                    (void)R->GroupEnd();
+                    return fail(CSLAM_ERR_HIP, "pf_resample_sharded: self counts differ (%zu / %zu)", sc, rcv);
+                }
+                if (sc > 0)
+                {
+                    CSLAM_HIP_TRY(hipMemcpyAsync(dRecvBuf + roff * rec, dSendBuf + soff * rec, sc * rec * sizeof(T),
+                                                 hipMemcpyDeviceToDevice, stream));
+                }
+            }
+            else
+            {
+                if (sc > 0)
+                {
+                    CSLAM_RCCL_TRY(R->Send(dSendBuf + soff * rec, sc * rec, dt, r, c->comm, stream));
+                }
+                if (rcv > 0)
+                {
+                    CSLAM_RCCL_TRY(R->Recv(dRecvBuf + roff * rec, rcv * rec, dt, r, c->comm, stream));
+                }
+            }
+            soff += sc;
+            roff += rcv;
+        }
+        CSLAM_RCCL_TRY(R->GroupEnd());
+        hipLaunchKernelGGL(pf_unpack_kernel<T>, dim3(L), dim3(256), 0, stream, store(), (const int*)nullptr, L, dRecvBuf);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return set_uniform_weight(1.0 / (double)N); // PF.cpp:495-499
+    }
+
     int get_particle(int i, void* w, void* Xv, void* Pv, void* XF, void* PF) override
     {
         if (i < 0 || i >= np)
@@ -913,6 +1174,83 @@ int cslam_pf_set_particle(cslam_pf_t h, int index, const void* w, const void* Xv
 {
     CSLAM_NEED(h);
     return B(h)->set_particle(index, w, Xv, Pv, XF, PF, nf);
+}
+
+int cslam_comm_unique_id(void* id_bytes)
+{
+    if (!id_bytes)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "comm_unique_id: null");
+    }
+    Rccl* R = rccl();
+    if (!R)
+    {
+        return fail(CSLAM_ERR_HIP, "comm_unique_id: librccl could not be loaded");
+    }
+    static_assert(sizeof(ncclUniqueId) == CSLAM_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    CSLAM_RCCL_TRY(R->GetUniqueId(&id));
+    std::memcpy(id_bytes, &id, sizeof(id));
+    return CSLAM_OK;
+}
+
+int cslam_comm_create(const void* id_bytes, int rank, int world, int device, cslam_comm_t* out)
+{
+    if (!id_bytes || !out || world < 1 || rank < 0 || rank >= world)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "comm_create: bad arguments");
+    }
+    *out    = nullptr;
+    Rccl* R = rccl();
+    if (!R)
+    {
+        return fail(CSLAM_ERR_HIP, "comm_create: librccl could not be loaded");
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess)
+    {
+        device = 0;
+    }
+    CSLAM_HIP_TRY(hipSetDevice(device));
+    Comm* c = new (std::nothrow) Comm();
+    if (!c)
+    {
+        return fail(CSLAM_ERR_ALLOC, "comm_create: out of host memory");
+    }
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess)
+    {
+        delete c;
+        return fail(CSLAM_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "rccl error");
+    }
+    c->rank   = rank;
+    c->world  = world;
+    c->device = device;
+    *out      = reinterpret_cast<cslam_comm_t>(c);
+    return CSLAM_OK;
+}
+
+int cslam_comm_destroy(cslam_comm_t c)
+{
+    if (!c)
+    {
+        return CSLAM_OK;
+    }
+    Comm* cc = reinterpret_cast<Comm*>(c);
+    if (Rccl* R = rccl())
+    {
+        (void)R->CommDestroy(cc->comm);
+    }
+    delete cc;
+    return CSLAM_OK;
+}
+
+int cslam_pf_resample_sharded(cslam_pf_t h, cslam_comm_t comm, const void* select, double n_effective,
+                              int resample_status, double* neff, int* resampled)
+{
+    CSLAM_NEED(h);
+    return B(h)->resample_sharded(reinterpret_cast<Comm*>(comm), select, n_effective, resample_status, neff, resampled);
 }
 
 } // extern "C"

@@ -47,6 +47,26 @@ __device__ inline T p_sym(const T* __restrict__ P, int ldp, int i, int j, int lo
     return direct ? P[(size_t)j * ldp + i] : P[(size_t)i * ldp + j];
 }
 
+// Pose stripe.  Columns 0..2 of P (= rows 0..2 by symmetry, and the 3 x 3 pose block) live in their OWN buffer
+//     Pv[c*ldp + i] = P[i, c],  c < 3, i < n,
+// which is always current: predict (EKF.cpp:439-443) and the heading observation only touch it, every update applies its
+// downdate to it at once (ekf_pose_downdate_kernel), and the pending W1 panels carry ZERO pose rows.  The P buffer's own
+// rows/columns 0..2 are dead storage (the P-GEMM may scribble there; get_state patches them from Pv).  This is what lets a
+// predict or a heading update run while the P-GEMM of the previous update is still sweeping P on another stream.
+template <typename T>
+__device__ inline T p_get(const T* __restrict__ P, const T* __restrict__ Pv, int ldp, int i, int j, int lower)
+{
+    if (j < 3)
+    {
+        return Pv[(size_t)j * ldp + i];
+    }
+    if (i < 3)
+    {
+        return Pv[(size_t)i * ldp + j];
+    }
+    return p_sym<T>(P, ldp, i, j, lower);
+}
+
 // EKF.cpp:354-404 for one observation. coef[0..4] = row 0 of H at columns {0,1,2,fx,fx+1},
 // coef[5..9] = row 1; v = innovation (EKF.cpp:117-118, bearing wrapped); fx = 0-based index of the
 // feature's x in the state (= fpos-1 of the reference).
@@ -223,7 +243,8 @@ __device__ inline void predict_pvv(const PredictArgs<T>& pp, T phi_old, const T*
 constexpr int kGatherObs = 1; // measured at N = 5000, m = 32: 11.1 us (8 per block), 10.2 (4), 9.5 (2), 8.7 (1): the kernel is a latency chain, more blocks win
 
 template <typename T>
-__global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X, const T* __restrict__ P, int ldp,
+__global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X, const T* __restrict__ P,
+                                                          const T* __restrict__ Pv, int ldp,
                                                           int n, const T* __restrict__ Z, const int* __restrict__ idf,
                                                           int m, T* __restrict__ PHT, int ldw, int lower,
                                                           T* __restrict__ sub = nullptr,
@@ -254,23 +275,23 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     int       fxe[kGatherObs];
     T         ea[kGatherObs], eb[kGatherObs];
     T         sa[kGatherObs][3], sb[kGatherObs][3]; // pp.valid, i < 3: rows 0..2 of the landmark's two columns
-    T         Pv[9];
+    T         Pvv[9];
     const T   phi_old = X[2];
 #pragma unroll
     for (int oo = 0; oo < kGatherObs; oo++)
     {
         fxe[oo] = 3 + 2 * idf[o0 + min(oo, no - 1)] - 2; // as observe_model_pose
-        ea[oo]  = p_sym<T>(P, ldp, il, fxe[oo], lower);
-        eb[oo]  = p_sym<T>(P, ldp, il, fxe[oo] + 1, lower);
+        ea[oo]  = p_get<T>(P, Pv, ldp, il, fxe[oo], lower);
+        eb[oo]  = p_get<T>(P, Pv, ldp, il, fxe[oo] + 1, lower);
     }
-    T p0 = P[(size_t)0 * ldp + il], p1 = P[(size_t)1 * ldp + il], p2 = P[(size_t)2 * ldp + il];
+    T p0 = Pv[(size_t)0 * ldp + il], p1 = Pv[(size_t)1 * ldp + il], p2 = Pv[(size_t)2 * ldp + il];
     if (pp.valid && i < 3)
     {
         for (int cc = 0; cc < 3; cc++)
         {
             for (int r = 0; r < 3; r++)
             {
-                Pv[r + 3 * cc] = P[(size_t)cc * ldp + r];
+                Pvv[r + 3 * cc] = Pv[(size_t)cc * ldp + r];
             }
         }
 #pragma unroll
@@ -278,8 +299,8 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         {
             for (int r = 0; r < 3; r++)
             {
-                sa[oo][r] = p_sym<T>(P, ldp, r, fxe[oo], lower);
-                sb[oo][r] = p_sym<T>(P, ldp, r, fxe[oo] + 1, lower);
+                sa[oo][r] = Pv[(size_t)r * ldp + fxe[oo]];
+                sb[oo][r] = Pv[(size_t)r * ldp + fxe[oo] + 1];
             }
         }
     }
@@ -330,7 +351,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         else // row i of Pvv
         {
             T out[9];
-            predict_pvv<T>(pp, phi_old, Pv, out);
+            predict_pvv<T>(pp, phi_old, Pvv, out);
             p0 = out[i];
             p1 = out[i + 3];
             p2 = out[i + 6];
@@ -439,7 +460,8 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
 //                              features that did not set a record).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) ekf_assoc_feature_kernel(const T* __restrict__ X, const T* __restrict__ P, int ldp,
+__global__ void __launch_bounds__(256) ekf_assoc_feature_kernel(const T* __restrict__ X, const T* __restrict__ P,
+                                                                 const T* __restrict__ Pv, int ldp,
                                                                  int n, T r00, T r10, T r01, T r11, int lower,
                                                                  T* __restrict__ out)
 {
@@ -466,7 +488,7 @@ __global__ void __launch_bounds__(256) ekf_assoc_feature_kernel(const T* __restr
 #pragma unroll
         for (int l = 0; l < 5; l++)
         {
-            p[l] = p_sym<T>(P, ldp, idx[l], idx[c], lower);
+            p[l] = p_get<T>(P, Pv, ldp, idx[l], idx[c], lower);
         }
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -602,8 +624,10 @@ template <typename T>
 __global__ void __launch_bounds__(256) ekf_pending_y_kernel(const T* __restrict__ X, int n, const T* __restrict__ Z,
                                                              const int* __restrict__ idf, int m,
                                                              const T* __restrict__ Wp, int ldw, int kp,
-                                                             T* __restrict__ Y)
+                                                             T* __restrict__ Y, const int* __restrict__ sgn = nullptr)
 {
+    // sgn (optional): columns with sgn[q] != 0 enter P with the opposite sign (P = Ps - Wp diag(+-1) Wp^T, see
+    // ekf_pose_step_kernel): their row of Y is negated, which is all the correction PHT -= Wp Y^T needs.
     __shared__ T   s_coef[10];
     __shared__ int s_fx;
     const int      o = blockIdx.x;
@@ -632,6 +656,11 @@ __global__ void __launch_bounds__(256) ekf_pending_y_kernel(const T* __restrict_
     y1 += s_coef[8] * wa;
     y1 += s_coef[9] * wb;
     const int k = 2 * m;
+    if (sgn != nullptr && sgn[q] != 0)
+    {
+        y0 = -y0;
+        y1 = -y1;
+    }
     Y[(size_t)q * k + 2 * o]     = y0;
     Y[(size_t)q * k + 2 * o + 1] = y1;
 }
@@ -692,78 +721,6 @@ __global__ void __launch_bounds__(256) ekf_pending_corr_kernel(int n, int m, con
                 *p   = *p - acc[c];
             }
         }
-    }
-}
-
-// predict under pending panels (EKF.cpp:439-443): F*(Ps - Wp Wp^T)*F^T = F Ps F^T - (F Wp)(F Wp)^T, so the
-// pose rows of every pending panel are transformed by Gv.  With the reference's n-4 stripe (quirk #2) the
-// last column's pose cross-covariance must NOT move: its stored value is adjusted by (Gv-I)*Wv*Wp[n-1,:]^T
-// so that the true value stays what the reference leaves there.  One workgroup; must run BEFORE the pose update.
-template <typename T>
-__global__ void __launch_bounds__(256) ekf_pending_predict_kernel(const T* __restrict__ X, T* __restrict__ P, int ldp,
-                                                                   int n, T v, T swa, T dt, T* __restrict__ Wp, int ldw,
-                                                                   int kp, int fix_last)
-{
-    __shared__ T s_red[256];
-    const T      phi = X[2];
-    const T      g02 = -v * dt * dsin(swa + phi);
-    const T      g12 = v * dt * dcos(swa + phi);
-    T            part = (T)0;
-    for (int q = threadIdx.x; q < kp; q += 256)
-    {
-        T*      w  = Wp + (size_t)q * ldw;
-        const T w2 = w[2];
-        if (fix_last)
-        {
-            part += w2 * w[n - 1];
-        }
-        w[0] = w[0] + g02 * w2; // rows of Gv: [1 0 g02; 0 1 g12; 0 0 1]
-        w[1] = w[1] + g12 * w2;
-    }
-    if (fix_last) // block-uniform
-    {
-        s_red[threadIdx.x] = part;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1)
-        {
-            if ((int)threadIdx.x < st)
-            {
-                s_red[threadIdx.x] += s_red[threadIdx.x + st];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0)
-        {
-            const T   d = s_red[0]; // Wv[2,:] . Wp[n-1,:]
-            const int c = n - 1;
-            P[(size_t)c * ldp + 0] += g02 * d;
-            P[(size_t)c * ldp + 1] += g12 * d;
-            P[(size_t)0 * ldp + c] += g02 * d;
-            P[(size_t)1 * ldp + c] += g12 * d;
-        }
-    }
-}
-
-// augment under pending panels (EKF.cpp:77-84): the new rows of the true P are Gv_a*P[0:3,:], so the new rows
-// of every pending panel are Gv_a*Wp[0:3,:].  Runs BEFORE ekf_augment_kernel appends the feature (it needs the
-// old X[2]); one workgroup.
-template <typename T>
-__global__ void __launch_bounds__(256) ekf_pending_augment_kernel(const T* __restrict__ X, int len, T r, T b,
-                                                                   T* __restrict__ Wp, int ldw, int kp)
-{
-    const T s = dsin(X[2] + b), c = dcos(X[2] + b);
-    for (int q = threadIdx.x; q < kp; q += 256)
-    {
-        T*      w  = Wp + (size_t)q * ldw;
-        const T w0 = w[0], w1 = w[1], w2 = w[2];
-        T       a0 = (T)1 * w0;
-        a0 += (T)0 * w1;
-        a0 += (-r * s) * w2;
-        T a1 = (T)0 * w0;
-        a1 += (T)1 * w1;
-        a1 += (r * c) * w2;
-        w[len]     = a0;
-        w[len + 1] = a1;
     }
 }
 
@@ -1380,295 +1337,6 @@ __global__ void __launch_bounds__(256, 3) ekf_downdate_f64(double* __restrict__ 
                 *ptr[cb * 4 + g] = v[cb * 4 + g];
             }
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K6: predict (EKF.cpp:406-455).  One workgroup: the barrier orders every read of the old pose and old
-// Pvv before they are overwritten.  stripe_w = n-4 (REF_EXACT, quirk #2) or n-3 (TEXTBOOK).
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(1024) ekf_predict_kernel(T* __restrict__ X, T* __restrict__ P, int ldp, int n, T v,
-                                                            T swa, T q00, T q10, T q01, T q11, T wb, T dt,
-                                                            int stripe_w, int lower)
-{
-    __shared__ T s_gv[9];
-    __shared__ T s_pvv[9];
-    __shared__ T s_pose[3];
-    const int    tid = threadIdx.x;
-    if (tid == 0)
-    {
-        T phi = X[2];
-        T s = dsin(swa + phi), c = dcos(swa + phi);
-        T Gv[9] = {(T)1, (T)0, (T)0, (T)0, (T)1, (T)0, -v * dt * s, v * dt * c, (T)1}; // column-major
-        T Gu[6] = {dt * c, dt * s, dt * dsin(swa) / wb, -v * dt * s, v * dt * c, v * dt * dcos(swa) / wb};
-        T Q[4]  = {q00, q10, q01, q11};
-        T Pv[9], t1[9], t2[9];
-        for (int cc = 0; cc < 3; cc++)
-        {
-            for (int r = 0; r < 3; r++)
-            {
-                Pv[r + 3 * cc] = P[(size_t)cc * ldp + r];
-            }
-        }
-        for (int cc = 0; cc < 3; cc++) // t1 = Gv*Pvv
-        {
-            for (int r = 0; r < 3; r++)
-            {
-                T acc = (T)0;
-                for (int l = 0; l < 3; l++)
-                {
-                    acc += Gv[r + 3 * l] * Pv[l + 3 * cc];
-                }
-                t1[r + 3 * cc] = acc;
-            }
-        }
-        for (int cc = 0; cc < 3; cc++) // t2 = t1*Gv^T
-        {
-            for (int r = 0; r < 3; r++)
-            {
-                T acc = (T)0;
-                for (int l = 0; l < 3; l++)
-                {
-                    acc += t1[r + 3 * l] * Gv[cc + 3 * l];
-                }
-                t2[r + 3 * cc] = acc;
-            }
-        }
-        T GuQ[6];
-        for (int cc = 0; cc < 2; cc++)
-        {
-            for (int r = 0; r < 3; r++)
-            {
-                T acc = (T)0;
-                for (int l = 0; l < 2; l++)
-                {
-                    acc += Gu[r + 3 * l] * Q[l + 2 * cc];
-                }
-                GuQ[r + 3 * cc] = acc;
-            }
-        }
-        for (int cc = 0; cc < 3; cc++)
-        {
-            for (int r = 0; r < 3; r++)
-            {
-                T acc = (T)0;
-                for (int l = 0; l < 2; l++)
-                {
-                    acc += GuQ[r + 3 * l] * Gu[cc + 3 * l];
-                }
-                s_pvv[r + 3 * cc] = t2[r + 3 * cc] + acc;
-            }
-        }
-        for (int e = 0; e < 9; e++)
-        {
-            s_gv[e] = Gv[e];
-        }
-        s_pose[0] = X[0] + v * dt * c;
-        s_pose[1] = X[1] + v * dt * s;
-        s_pose[2] = pi2pi<T>(X[2] + v * dt * dsin(swa) / wb);
-    }
-    __syncthreads();
-    // cross-covariance stripe: P[0:3, 3:3+w] = Gv * stripe, mirrored (EKF.cpp:442-443)
-    for (int j = tid; j < stripe_w; j += blockDim.x)
-    {
-        const int c  = 3 + j;
-        T         a0 = p_sym<T>(P, ldp, 0, c, lower), a1 = p_sym<T>(P, ldp, 1, c, lower), a2 = p_sym<T>(P, ldp, 2, c, lower);
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-        {
-            T acc = (T)0;
-            acc += s_gv[r + 0] * a0;
-            acc += s_gv[r + 3] * a1;
-            acc += s_gv[r + 6] * a2;
-            P[(size_t)c * ldp + r] = acc;
-            P[(size_t)r * ldp + c] = acc;
-        }
-    }
-    if (tid < 9)
-    {
-        P[(size_t)(tid / 3) * ldp + (tid % 3)] = s_pvv[tid];
-    }
-    if (tid < 3)
-    {
-        X[tid] = s_pose[tid];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K7: augment by one feature (EKF.cpp:28-91), O(n): the covariance buffer is preallocated, so the
-// reference's copy-resize-zero-copy (EKF.cpp:67-71) disappears.  One workgroup.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(1024) ekf_augment_kernel(T* __restrict__ X, T* __restrict__ P, int ldp, int len, T r,
-                                                            T b, T r00, T r10, T r01, T r11, int lower)
-{
-    __shared__ T s_gv[6];
-    const int    tid = threadIdx.x;
-    if (tid == 0)
-    {
-        T s = dsin(X[2] + b), c = dcos(X[2] + b);
-        X[len]     = X[0] + (r * c);
-        X[len + 1] = X[1] + (r * s);
-        T Gv[6] = {(T)1, (T)0, (T)0, (T)1, -r * s, r * c}; // 2x3 column-major
-        T Gz[4] = {c, s, -r * s, r * c};
-        T R[4]  = {r00, r10, r01, r11};
-        T GvP[6];
-        for (int cc = 0; cc < 3; cc++)
-        {
-            for (int rr = 0; rr < 2; rr++)
-            {
-                T acc = (T)0;
-                for (int l = 0; l < 3; l++)
-                {
-                    acc += Gv[rr + 2 * l] * P[(size_t)cc * ldp + l];
-                }
-                GvP[rr + 2 * cc] = acc;
-            }
-        }
-        T GzR[4];
-        for (int cc = 0; cc < 2; cc++)
-        {
-            for (int rr = 0; rr < 2; rr++)
-            {
-                T acc = (T)0;
-                for (int l = 0; l < 2; l++)
-                {
-                    acc += Gz[rr + 2 * l] * R[l + 2 * cc];
-                }
-                GzR[rr + 2 * cc] = acc;
-            }
-        }
-        for (int cc = 0; cc < 2; cc++)
-        {
-            for (int rr = 0; rr < 2; rr++)
-            {
-                T a1 = (T)0;
-                for (int l = 0; l < 3; l++)
-                {
-                    a1 += GvP[rr + 2 * l] * Gv[cc + 2 * l];
-                }
-                T a2 = (T)0;
-                for (int l = 0; l < 2; l++)
-                {
-                    a2 += GzR[rr + 2 * l] * Gz[cc + 2 * l];
-                }
-                P[(size_t)(len + cc) * ldp + len + rr] = a1 + a2; // EKF.cpp:74
-            }
-        }
-        for (int e = 0; e < 6; e++)
-        {
-            s_gv[e] = Gv[e];
-        }
-    }
-    __syncthreads();
-    // EKF.cpp:77-78, 83-84: new rows = Gv * P[0:3, 0:len], mirrored into the new columns
-    for (int j = tid; j < len; j += blockDim.x)
-    {
-        T a0 = p_sym<T>(P, ldp, 0, j, lower), a1 = p_sym<T>(P, ldp, 1, j, lower), a2 = p_sym<T>(P, ldp, 2, j, lower);
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++)
-        {
-            T acc = (T)0;
-            acc += s_gv[rr + 0] * a0;
-            acc += s_gv[rr + 2] * a1;
-            acc += s_gv[rr + 4] * a2;
-            P[(size_t)j * ldp + len + rr]   = acc;
-            P[(size_t)(len + rr) * ldp + j] = acc;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K8: heading observation (EKF.cpp:328-352 -> josephUpdate slam.h:700-725) with H = e_2^T.
-// The dense Joseph form C*P*C^T + W*R*W^T, C = I - W*H, is evaluated exactly but using the structure of
-// C (identity except column 2):   CP[i,j] = P[i,j] - W[i]*P[2,j];   (CP*C^T)[i,j] = CP[i,j] - CP[i,2]*W[j]
-// for j != 2 and CP[i,2]*(1 - W[2]) for j == 2;   plus (W[i]*R)*W[j];   plus FLT_MIN on the diagonal
-// (slam.h:719).  O(n^2) instead of the reference's two n^3 GEMMs.
-//   prep kernel (one workgroup): p = P[:,2], r = P[2,:], S = P22 + R, W = p * (1/S), X += W*V, scratch.
-//   apply kernel: elementwise over P.
-// scratch layout: w[ldp], cp2[ldp] (= p - W*P22), r[ldp], then scalars {R, 1-W[2]}.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(1024) ekf_heading_prep_kernel(T* __restrict__ X, const T* __restrict__ P, int ldp,
-                                                                 int n, T phi, T R, T* __restrict__ w,
-                                                                 T* __restrict__ cp2, T* __restrict__ rrow,
-                                                                 T* __restrict__ scal, int lower)
-{
-    __shared__ T s_v, s_si, s_p22, s_omw2;
-    const int    tid = threadIdx.x;
-    if (tid == 0)
-    {
-        s_v    = pi2pi<T>(phi - X[2]);
-        T p22  = P[(size_t)2 * ldp + 2];
-        T S    = p22 + R;  // H*PHT + R
-        s_si   = (T)1 / S; // S.inverse(); makeSymmetric of a 1x1 changes nothing
-        s_p22  = p22;
-        s_omw2 = (T)1 - p22 * s_si; // C[2,2] = 1 - W[2]
-    }
-    __syncthreads();
-    const T V = s_v, SI = s_si, p22 = s_p22, omw2 = s_omw2;
-    for (int i = tid; i < n; i += blockDim.x)
-    {
-        T pi_   = P[(size_t)2 * ldp + i]; // column 2 (PHT = P*H^T)
-        T wi    = pi_ * SI;               // W = PHT*SI
-        w[i]    = wi;
-        cp2[i]  = (i == 2) ? omw2 * p22 : pi_ - wi * p22; // (C*P)[i,2]; row 2 of C is (1-W[2]) e_2^T
-        rrow[i] = p_sym<T>(P, ldp, 2, i, lower);          // row 2 (its mirror, column 2, in lower mode)
-        X[i]    = X[i] + wi * V;
-    }
-    if (tid == 0)
-    {
-        scal[0] = R;
-        scal[1] = omw2;
-    }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) ekf_heading_apply_kernel(T* __restrict__ P, int ldp, int n,
-                                                                 const T* __restrict__ w, const T* __restrict__ cp2,
-                                                                 const T* __restrict__ rrow,
-                                                                 const T* __restrict__ scal, T tiny, int lower)
-{
-    // block: 256 rows x 16 columns
-    const int i  = blockIdx.x * 256 + threadIdx.x;
-    const int j0 = blockIdx.y * 16;
-    if (i >= n)
-    {
-        return;
-    }
-    if (lower && ((blockIdx.x * 256 + 255) >> 7) < (j0 >> 7))
-    {
-        return; // every element of this block lies in tiles above the diagonal: not maintained
-    }
-    const T wi = w[i], ci2 = cp2[i];
-    const T R = scal[0], omw2 = scal[1];
-    const T wir = wi * R;
-    for (int jj = 0; jj < 16; jj++)
-    {
-        const int j = j0 + jj;
-        if (j >= n)
-        {
-            break;
-        }
-        T* p   = P + (size_t)j * ldp + i;
-        T  cp  = (i == 2) ? omw2 * rrow[j] : *p - wi * rrow[j]; // (C*P)[i,j]
-        T  wj  = w[j];
-        T  out;
-        if (j == 2)
-        {
-            out = ci2 * omw2;
-        }
-        else
-        {
-            out = cp + ci2 * (-wj);
-        }
-        out = out + wir * wj;
-        if (i == j)
-        {
-            out = out + tiny;
-        }
-        *p = out;
     }
 }
 

@@ -10,7 +10,7 @@
 //   ekf_downdate_psym4_f32<.,NCH> the P-GEMM P -= W1*W1^T: persistent, symmetric (block-lower storage), dynamic tile
 //                                 tickets, every memory operation issued from inside the MFMA loop; NCH = 2 (k <= 64)
 //                                 or 4 (k <= 128) chunks of 32 columns.
-//   ekf_predict_stripe_kernel     EKF.cpp:406-455 in one launch (when a predict is not absorbed by the next update).
+//   (predict, heading, augment and the pose-stripe downdate live in ekf_pose_kernels.hpp)
 // Other shapes, A/B switches and earlier generations (selected by the CSLAM_TUNE_* variables, see cslam_ekf.hip):
 //   ekf_factor_small_kernel<T,K>  one wave holds the matrix a row per lane; every multiplier broadcast by v_readlane
 //                                 (k <= 16, and f64).
@@ -1688,9 +1688,9 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
                                                           const float* __restrict__ Bt, int ldb,
                                                           const float* __restrict__ u, float* __restrict__ OUT, int ldo,
                                                           float* __restrict__ X, const float* __restrict__ pred = nullptr,
-                                                          int pred_w = 0, float* __restrict__ P = nullptr, int ldp = 0,
-                                                          int lower = 0)
+                                                          int pred_w = 0, float* __restrict__ P = nullptr, int ldp = 0)
 {
+    // (P here is the pose stripe Pv, see p_get: the predicted stripe and pose block are committed there)
     // pred != nullptr (gain, XUPD): a predict() was applied on the fly by the gather and factor kernels (PredictArgs);
     // this kernel commits it: the column-tile-0 workgroups write the predicted stripe and Pvv into P and add the state
     // correction to the PREDICTED pose.  pred = {g02, g12, pose (3), Pvv (9)} from the factor kernel.
@@ -1768,15 +1768,11 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
                 X[r] = ((r < 3) ? pred[2 + r] : X[r]) + xs;
                 if (r >= 3)
                 {
-                    if (r - 3 < pred_w) // column r of the cross-covariance stripe, mirrored (EKF.cpp:442-443)
+                    if (r - 3 < pred_w) // column r of the cross-covariance stripe (EKF.cpp:442-443), in the pose stripe Pv
                     {
-                        const float a0 = p_sym<float>(P, ldp, 0, r, lower), a1 = p_sym<float>(P, ldp, 1, r, lower),
-                                    a2 = p_sym<float>(P, ldp, 2, r, lower);
+                        const float a0 = P[(size_t)0 * ldp + r], a1 = P[(size_t)1 * ldp + r], a2 = P[(size_t)2 * ldp + r];
                         float o0, o1, o2;
                         predict_stripe_col<float>(pred[0], pred[1], a0, a1, a2, &o0, &o1, &o2);
-                        P[(size_t)r * ldp + 0] = o0;
-                        P[(size_t)r * ldp + 1] = o1;
-                        P[(size_t)r * ldp + 2] = o2;
                         P[(size_t)0 * ldp + r] = o0;
                         P[(size_t)1 * ldp + r] = o1;
                         P[(size_t)2 * ldp + r] = o2;
@@ -2649,130 +2645,6 @@ __global__ void __launch_bounds__(256) ekf_mirror_upper_kernel(T* __restrict__ P
             P[(size_t)dj * ldp + di] = tile[tx][c];
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K6 (EKF.cpp:406-455) in one launch: the cross-covariance stripe on many CUs (every block reads the old heading
-// and writes only the stripe), then the block that finishes LAST (atomic ticket) updates Pvv and the pose -- by
-// then every other block has consumed the old heading.  The ticket counter is reset by that block for the next
-// launch (launches on one stream are ordered).  Same arithmetic and summation order as ekf_predict_kernel.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) ekf_predict_stripe_kernel(T* __restrict__ X, T* __restrict__ P, int ldp, T v, T swa,
-                                                                  T q00, T q10, T q01, T q11, T wb, T dt, int stripe_w,
-                                                                  int lower, int* __restrict__ done)
-{
-    __shared__ int s_last;
-    const int      j = blockIdx.x * 256 + threadIdx.x;
-    if (j < stripe_w)
-    {
-        const T phi = X[2];
-        const T g02 = -v * dt * dsin(swa + phi); // Gv = [[1,0,g02],[0,1,g12],[0,0,1]]  (EKF.cpp:419-428)
-        const T g12 = v * dt * dcos(swa + phi);
-        const int c  = 3 + j;
-        const T   a0 = p_sym<T>(P, ldp, 0, c, lower), a1 = p_sym<T>(P, ldp, 1, c, lower), a2 = p_sym<T>(P, ldp, 2, c, lower);
-        // rows of Gv * stripe in the dense summation order (zeros of Gv included)
-        T o0 = (T)1 * a0;
-        o0 += (T)0 * a1;
-        o0 += g02 * a2;
-        T o1 = (T)0 * a0;
-        o1 += (T)1 * a1;
-        o1 += g12 * a2;
-        T o2 = (T)0 * a0;
-        o2 += (T)0 * a1;
-        o2 += (T)1 * a2;
-        P[(size_t)c * ldp + 0] = o0;
-        P[(size_t)c * ldp + 1] = o1;
-        P[(size_t)c * ldp + 2] = o2;
-        P[(size_t)0 * ldp + c] = o0;
-        P[(size_t)1 * ldp + c] = o1;
-        P[(size_t)2 * ldp + c] = o2;
-    }
-    __syncthreads(); // every thread of this block has read the old heading (its value fed the stores above)
-    if (threadIdx.x == 0)
-    {
-        const int t = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last      = (t == (int)gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (s_last == 0 || threadIdx.x != 0)
-    {
-        return;
-    }
-    *done = 0;
-    // Pvv = Gv Pvv Gv^T + Gu Q Gu^T and the pose (EKF.cpp:430-440, 445-452)
-    T phi = X[2];
-    T s = dsin(swa + phi), c = dcos(swa + phi);
-    T Gv[9] = {(T)1, (T)0, (T)0, (T)0, (T)1, (T)0, -v * dt * s, v * dt * c, (T)1}; // column-major
-    T Gu[6] = {dt * c, dt * s, dt * dsin(swa) / wb, -v * dt * s, v * dt * c, v * dt * dcos(swa) / wb};
-    T Q[4]  = {q00, q10, q01, q11};
-    T Pv[9], t1[9], t2[9], pvv[9];
-    for (int cc = 0; cc < 3; cc++)
-    {
-        for (int r = 0; r < 3; r++)
-        {
-            Pv[r + 3 * cc] = P[(size_t)cc * ldp + r];
-        }
-    }
-    for (int cc = 0; cc < 3; cc++) // t1 = Gv*Pvv
-    {
-        for (int r = 0; r < 3; r++)
-        {
-            T acc = (T)0;
-            for (int l = 0; l < 3; l++)
-            {
-                acc += Gv[r + 3 * l] * Pv[l + 3 * cc];
-            }
-            t1[r + 3 * cc] = acc;
-        }
-    }
-    for (int cc = 0; cc < 3; cc++) // t2 = t1*Gv^T
-    {
-        for (int r = 0; r < 3; r++)
-        {
-            T acc = (T)0;
-            for (int l = 0; l < 3; l++)
-            {
-                acc += t1[r + 3 * l] * Gv[cc + 3 * l];
-            }
-            t2[r + 3 * cc] = acc;
-        }
-    }
-    T GuQ[6];
-    for (int cc = 0; cc < 2; cc++)
-    {
-        for (int r = 0; r < 3; r++)
-        {
-            T acc = (T)0;
-            for (int l = 0; l < 2; l++)
-            {
-                acc += Gu[r + 3 * l] * Q[l + 2 * cc];
-            }
-            GuQ[r + 3 * cc] = acc;
-        }
-    }
-    for (int cc = 0; cc < 3; cc++)
-    {
-        for (int r = 0; r < 3; r++)
-        {
-            T acc = (T)0;
-            for (int l = 0; l < 2; l++)
-            {
-                acc += GuQ[r + 3 * l] * Gu[cc + 3 * l];
-            }
-            pvv[r + 3 * cc] = t2[r + 3 * cc] + acc;
-        }
-    }
-    const T x0 = X[0] + v * dt * c;
-    const T x1 = X[1] + v * dt * s;
-    const T x2 = pi2pi<T>(X[2] + v * dt * dsin(swa) / wb);
-    for (int e = 0; e < 9; e++)
-    {
-        P[(size_t)(e / 3) * ldp + (e % 3)] = pvv[e];
-    }
-    X[0] = x0;
-    X[1] = x1;
-    X[2] = x2;
 }
 
 } // namespace cslam

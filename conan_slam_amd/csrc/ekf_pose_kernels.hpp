@@ -1,0 +1,409 @@
+// ekf_pose_kernels.hpp -- the O(n) kernels that work on the pose stripe Pv (see p_get in ekf_kernels.hpp):
+//
+//   ekf_pose_step_kernel      EKF::predict (EKF.cpp:406-455) and / or EKF::observeHeading (EKF.cpp:328-352 with
+//                             josephUpdate slam.h:700-725) in ONE launch -- the reference's driver calls the two back to
+//                             back on every control step (test/main.cpp:165-168).
+//   ekf_pose_downdate_kernel  the pose-stripe share of slam.h:260, P[:,0:3] -= W1 * W1[0:3,:]^T, applied right behind
+//                             the gain kernel; it then ZEROES the pose rows of the W1 panel, so that the pending-panel
+//                             algebra (P = Ps - Wp Wp^T) never touches the stripe.
+//   ekf_augment_kernel        EKF::addOneNewFeature (EKF.cpp:28-91), O(n) with the preallocated buffers.
+//   ekf_patch_pose_kernel     Pv -> rows/columns 0..2 of the P buffer (get_state).
+//
+// Why the heading update is O(n) here.  With H = e_2^T, p = P[:,2], S = P22 + R, W = p/S, the Joseph form of
+// slam.h:713-718 is, for a symmetric P,
+//     (I - W H) P (I - W H)^T + W R W^T  =  P - p p^T / S                                   (exactly),
+// i.e. ONE more rank-1 downdate of the same kind the update's W1 panels are: the column w = p / sqrt(S) is appended to
+// the pending panels (applied by the next P-GEMM together with them) and only the pose stripe, which must stay current,
+// is updated directly: P'[i,c] = P[i,c] - p_i p_c / S for c = 0,1 and P'[i,2] = p_i (R/S) -- the latter WITHOUT the
+// cancellation 1 - P22/S that any evaluation of C = I - W H in floating point suffers (R/S ~ 1e-6 with the
+// reference's sigma = 0.01 deg).  The reference's dense form costs 4 n^3 flops per control step; the earlier O(n^2)
+// form of this engine swept all of P; this one reads and writes 3 n scalars.
+#pragma once
+
+#include "ekf_kernels.hpp"
+
+namespace cslam
+{
+
+template <typename T>
+struct HeadingArgs
+{
+    int valid;
+    T   phi; // observed heading
+    T   R;   // sigmaPhi^2 (EKF.cpp:337-343)
+};
+
+// grid = ceil(n_pad/256) x 256 threads.  wcol: the pending column the heading update appends (n_pad entries written,
+// zeros in rows 0..2 and [n, n_pad)), or nullptr without a heading update.  done: ticket counter (reset by the last
+// workgroup, which is also the one that rewrites the 3 x 3 pose block and the pose -- everybody else has consumed the
+// old values by then).
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_pose_step_kernel(T* __restrict__ X, T* __restrict__ Pv, int ldp, int n,
+                                                             int n_pad, PredictArgs<T> pp, HeadingArgs<T> hd,
+                                                             T* __restrict__ wcol, int* __restrict__ sgn_out,
+                                                             int* __restrict__ neg_count, int* __restrict__ done)
+{
+    // sgn_out / neg_count: the reference's Joseph form is finite for S = P22 + R < 0 too (an indefinite P, which
+    // REF_EXACT's gain produces: SURVEY 2.1 #1/#3) and equals P - p p^T / S there as well, i.e. P + w w^T with
+    // w = p / sqrt(|S|): the column is stored with *sgn_out = 1 and counted in *neg_count; the pending-panel correction
+    // flips its sign (ekf_pending_y_kernel) and ekf_negcol_fix_kernel adds 2 w w^T in front of the P-GEMM.
+    __shared__ int s_last;
+    // ---- inputs every workgroup needs: the old pose and the old 3 x 3 block (uniform loads)
+    T pvv_old[9], pvv[9];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++)
+    {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+        {
+            pvv_old[r + 3 * cc] = Pv[(size_t)cc * ldp + r];
+        }
+    }
+    const T x0 = X[0], x1 = X[1], x2 = X[2];
+    T       px = x0, py = x1, pphi = x2;
+    T       g02 = (T)0, g12 = (T)0;
+    if (pp.valid)
+    {
+        predict_gv<T>(pp, x2, &g02, &g12);
+        predict_pvv<T>(pp, x2, pvv_old, pvv);
+        predicted_pose<T>(pp, X, &px, &py, &pphi);
+    }
+    else
+    {
+#pragma unroll
+        for (int e = 0; e < 9; e++)
+        {
+            pvv[e] = pvv_old[e];
+        }
+    }
+    // heading: column 2 of the (predicted) pose block, S, 1/S, the innovation
+    const T pc0 = pvv[0 + 6], pc1 = pvv[1 + 6], p22 = pvv[2 + 6];
+    const T S   = p22 + hd.R;
+    const T si  = (T)1 / S;
+    const T rs  = (T)1 / dsqrt(dabs(S));
+    const T ros = hd.R * si; // R/S = 1 - P22/S without the cancellation
+    const T vin = hd.valid ? pi2pi<T>(hd.phi - pphi) : (T)0;
+
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 && i < n)
+    {
+        T a0 = Pv[(size_t)0 * ldp + i], a1 = Pv[(size_t)1 * ldp + i], a2 = Pv[(size_t)2 * ldp + i];
+        if (pp.valid && (i - 3) < pp.w) // column i of the stripe P[0:3, 3:3+w] = Gv * stripe, mirrored (EKF.cpp:442-443)
+        {
+            T o0, o1, o2;
+            predict_stripe_col<T>(g02, g12, a0, a1, a2, &o0, &o1, &o2);
+            a0 = o0;
+            a1 = o1;
+            a2 = o2;
+        }
+        if (hd.valid)
+        {
+            const T pi_ = a2;       // p_i = P[i,2]
+            const T wi  = pi_ * si; // W = PHT * SI (slam.h:712)
+            a0          = a0 - wi * pc0;
+            a1          = a1 - wi * pc1;
+            a2          = pi_ * ros;
+            X[i]        = X[i] + wi * vin; // slam.h:713
+            wcol[i]     = pi_ * rs;
+        }
+        Pv[(size_t)0 * ldp + i] = a0;
+        Pv[(size_t)1 * ldp + i] = a1;
+        Pv[(size_t)2 * ldp + i] = a2;
+    }
+    else if (hd.valid && i < n_pad) // rows 0..2 (the stripe is never pending) and the padding rows
+    {
+        wcol[i] = (T)0;
+    }
+    __syncthreads(); // every thread of this workgroup has consumed the old pose / pose block
+    if (threadIdx.x == 0)
+    {
+        const int t = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last      = (t == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last == 0 || threadIdx.x != 0)
+    {
+        return;
+    }
+    *done = 0;
+    T out[9];
+    T xo[3] = {px, py, pphi};
+    if (hd.valid && sgn_out != nullptr)
+    {
+        const int neg = (S > (T)0) ? 0 : 1;
+        *sgn_out      = neg;
+        if (neg)
+        {
+            atomicAdd(neg_count, 1);
+        }
+    }
+    if (hd.valid)
+    {
+        const T pcol[3] = {pc0, pc1, p22};                      // P[r,2]
+        const T prow[3] = {pvv[2 + 0], pvv[2 + 3], pvv[2 + 6]}; // P[2,c]
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+        {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+            {
+                T val;
+                if (cc == 2)
+                {
+                    val = pcol[r] * ros;
+                }
+                else if (r == 2)
+                {
+                    val = prow[cc] * ros;
+                }
+                else
+                {
+                    val = pvv[r + 3 * cc] - (pcol[r] * si) * prow[cc];
+                }
+                out[r + 3 * cc] = val;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+        {
+            xo[r] = xo[r] + (pcol[r] * si) * vin;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int e = 0; e < 9; e++)
+        {
+            out[e] = pvv[e];
+        }
+    }
+    for (int e = 0; e < 9; e++)
+    {
+        Pv[(size_t)(e / 3) * ldp + (e % 3)] = out[e];
+    }
+    X[0] = xo[0];
+    X[1] = xo[1];
+    X[2] = xo[2];
+}
+
+// Pose-stripe downdate behind the gain kernel: Pv[:, c] -= sum_q W1[:, q] * W1[c, q] (q ascending, as the dense
+// product of slam.h:260 sums), c = 0..2; then the LAST workgroup zeroes W1[0:3, 0:k8) (everybody has read those rows by
+// then) after saving them to wv_out (3 x k, row c at wv_out + c*k: what cslam_ekf_debug_last_update reports).
+// grid = ceil(n/256) x 256.
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_pose_downdate_kernel(T* __restrict__ W1, int ldw, int k, int k8, int n,
+                                                                 T* __restrict__ Pv, int ldp, T* __restrict__ wv_out,
+                                                                 int* __restrict__ done)
+{
+    constexpr int QC = 128;
+    __shared__ T   s_wv[3][QC];
+    __shared__ int s_last;
+    const int      i  = blockIdx.x * 256 + threadIdx.x;
+    const int      il = min(i, n - 1);
+    T              acc0 = (T)0, acc1 = (T)0, acc2 = (T)0;
+    for (int q0 = 0; q0 < k; q0 += QC)
+    {
+        const int qn = min(QC, k - q0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < 3 * qn; e += 256)
+        {
+            const int c = e / qn, q = e - c * qn;
+            const T   v = W1[(size_t)(q0 + q) * ldw + c];
+            s_wv[c][q]  = v;
+            if (blockIdx.x == 0)
+            {
+                wv_out[(size_t)c * k + q0 + q] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int q = 0; q < qn; q++)
+        {
+            const T w = W1[(size_t)(q0 + q) * ldw + il];
+            acc0 += w * s_wv[0][q];
+            acc1 += w * s_wv[1][q];
+            acc2 += w * s_wv[2][q];
+        }
+    }
+    if (i < n)
+    {
+        Pv[(size_t)0 * ldp + i] -= acc0;
+        Pv[(size_t)1 * ldp + i] -= acc1;
+        Pv[(size_t)2 * ldp + i] -= acc2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int t = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last      = (t == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last == 0)
+    {
+        return;
+    }
+    if (threadIdx.x == 0)
+    {
+        *done = 0;
+    }
+    for (int e = threadIdx.x; e < 3 * k8; e += 256)
+    {
+        W1[(size_t)(e / 3) * ldw + (e % 3)] = (T)0;
+    }
+}
+
+// Exceptional path of the heading update (see ekf_pose_step_kernel): for every pending column q of this region with
+// sgn[q] != 0 the map block needs P += w_q w_q^T; the P-GEMM that follows subtracts w_q w_q^T, so 2 w_q w_q^T is added
+// here.  Launched in front of a P-GEMM whose region holds heading columns; exits at once when *neg_count == 0 (the
+// normal case).  Persistent: workgroup b takes tiles b, b + grid, ... (tile_list: the block-lower tiles, or nullptr
+// for every tile of the full matrix).
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_negcol_fix_kernel(T* __restrict__ P, int ldp, int n, const T* __restrict__ W,
+                                                              int ldw, int kp, const int* __restrict__ sgn,
+                                                              const int* __restrict__ neg_count,
+                                                              const int2* __restrict__ tile_list, int ntiles, int tiles_1d)
+{
+    if (*neg_count == 0)
+    {
+        return;
+    }
+    for (int tt = blockIdx.x; tt < ntiles; tt += gridDim.x)
+    {
+        const int2 t = tile_list ? tile_list[tt] : make_int2(tt % tiles_1d, tt / tiles_1d);
+        for (int e = threadIdx.x; e < 128 * 128; e += 256)
+        {
+            const int i = t.x * 128 + (e & 127), j = t.y * 128 + (e >> 7);
+            if (i >= n || j >= n)
+            {
+                continue;
+            }
+            T acc = (T)0;
+            for (int q = 0; q < kp; q++)
+            {
+                if (sgn[q])
+                {
+                    acc += W[(size_t)q * ldw + i] * W[(size_t)q * ldw + j];
+                }
+            }
+            P[(size_t)j * ldp + i] += (T)2 * acc;
+        }
+    }
+}
+
+// EKF.cpp:28-91 for one new feature observed at (r, b): X grows by 2, the new rows/columns of P are Gv*P[0:3, :]
+// (EKF.cpp:77-84, from the pose stripe, which is current), the new 2 x 2 block is Gv Pvv Gv^T + Gz R Gz^T (EKF.cpp:74).
+// The pending W1 panels keep ZERO rows for the new feature (their rows beyond n are zero), which is exactly right: the
+// values written here are those of the true P.  One workgroup (the barrier orders the read of X[2] before X grows).
+template <typename T>
+__global__ void __launch_bounds__(1024) ekf_augment_kernel(T* __restrict__ X, T* __restrict__ P, T* __restrict__ Pv,
+                                                            int ldp, int len, T r, T b, T r00, T r10, T r01, T r11,
+                                                            int lower)
+{
+    __shared__ T s_gv[6];
+    const int    tid = threadIdx.x;
+    if (tid == 0)
+    {
+        T s = dsin(X[2] + b), c = dcos(X[2] + b);
+        X[len]     = X[0] + (r * c);
+        X[len + 1] = X[1] + (r * s);
+        T Gv[6] = {(T)1, (T)0, (T)0, (T)1, -r * s, r * c}; // 2x3 column-major
+        T Gz[4] = {c, s, -r * s, r * c};
+        T R[4]  = {r00, r10, r01, r11};
+        T GvP[6];
+        for (int cc = 0; cc < 3; cc++)
+        {
+            for (int rr = 0; rr < 2; rr++)
+            {
+                T acc = (T)0;
+                for (int l = 0; l < 3; l++)
+                {
+                    acc += Gv[rr + 2 * l] * Pv[(size_t)cc * ldp + l];
+                }
+                GvP[rr + 2 * cc] = acc;
+            }
+        }
+        T GzR[4];
+        for (int cc = 0; cc < 2; cc++)
+        {
+            for (int rr = 0; rr < 2; rr++)
+            {
+                T acc = (T)0;
+                for (int l = 0; l < 2; l++)
+                {
+                    acc += Gz[rr + 2 * l] * R[l + 2 * cc];
+                }
+                GzR[rr + 2 * cc] = acc;
+            }
+        }
+        for (int cc = 0; cc < 2; cc++)
+        {
+            for (int rr = 0; rr < 2; rr++)
+            {
+                T a1 = (T)0;
+                for (int l = 0; l < 3; l++)
+                {
+                    a1 += GvP[rr + 2 * l] * Gv[cc + 2 * l];
+                }
+                T a2 = (T)0;
+                for (int l = 0; l < 2; l++)
+                {
+                    a2 += GzR[rr + 2 * l] * Gz[cc + 2 * l];
+                }
+                P[(size_t)(len + cc) * ldp + len + rr] = a1 + a2; // EKF.cpp:74
+            }
+        }
+        for (int e = 0; e < 6; e++)
+        {
+            s_gv[e] = Gv[e];
+        }
+    }
+    __syncthreads();
+    // EKF.cpp:77-78, 83-84: new rows = Gv * P[0:3, 0:len], mirrored into the new columns
+    for (int j = tid; j < len; j += blockDim.x)
+    {
+        const T a0 = Pv[(size_t)0 * ldp + j], a1 = Pv[(size_t)1 * ldp + j], a2 = Pv[(size_t)2 * ldp + j];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+        {
+            T acc = (T)0;
+            acc += s_gv[rr + 0] * a0;
+            acc += s_gv[rr + 2] * a1;
+            acc += s_gv[rr + 4] * a2;
+            if (j < 3)
+            {
+                Pv[(size_t)j * ldp + len + rr] = acc; // pose columns of the new rows: the stripe
+            }
+            else
+            {
+                P[(size_t)j * ldp + len + rr] = acc;
+                if (!lower || ((j >> 7) == ((len + rr) >> 7)))
+                {
+                    P[(size_t)(len + rr) * ldp + j] = acc; // the mirror exists under full storage / inside a diagonal tile
+                }
+            }
+        }
+    }
+}
+
+// rows / columns 0..2 of the P buffer <- Pv (before P is handed to the host); grid = ceil(n/256) x 256
+template <typename T>
+__global__ void __launch_bounds__(256) ekf_patch_pose_kernel(T* __restrict__ P, const T* __restrict__ Pv, int ldp, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+        const T v              = Pv[(size_t)c * ldp + i];
+        P[(size_t)c * ldp + i] = v;
+        if (i >= 3)
+        {
+            P[(size_t)i * ldp + c] = v;
+        }
+    }
+}
+
+} // namespace cslam

@@ -988,6 +988,105 @@ __global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w
     }
 }
 
+// The stratified selection alone (PF.cpp:559-574) on ALREADY NORMALISED weights: the sharded resample runs it on every
+// rank over the all-gathered weights of the whole set (identical input -> identical keep[] everywhere).  Same running
+// sum (one lane, particle dtype, index order) and the same search as pf_resample_plan_kernel.  One workgroup.
+template <typename T>
+__global__ void __launch_bounds__(256) pf_keep_kernel(const T* __restrict__ w, int np, const T* __restrict__ select,
+                                                       int* __restrict__ keep)
+{
+    __shared__ T s_cum[kPfPlanMax];
+    for (int i = threadIdx.x; i < np; i += 256)
+    {
+        s_cum[i] = w[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        T run = s_cum[0];
+        for (int i = 1; i < np; i++)
+        {
+            run      = run + s_cum[i];
+            s_cum[i] = run;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < np; c += 256)
+    {
+        const T sc = select[c];
+        int     lo = 0, hi = np;
+        while (lo < hi)
+        {
+            const int mid = (lo + hi) >> 1;
+            if (sc < s_cum[mid])
+            {
+                hi = mid;
+            }
+            else
+            {
+                lo = mid + 1;
+            }
+        }
+        keep[c] = (lo < np) ? lo : 0;
+    }
+}
+
+// Who sends what where, on the device.  Global slot g lives on rank g / L at local index g % L; it is
+// refilled from global particle keep[g], which lives on rank keep[g] / L.  keep[] is non-decreasing (select is
+// increasing), so for the slots of one destination the source ranks come in ascending order and, within one source,
+// in ascending g: no sorting is needed anywhere.
+//   send_idx[j]   local index of the j-th particle this rank sends = keep[g] - rank*L over all g whose source is this
+//                 rank, ascending g (hence grouped by destination rank)
+//   counts[d]             records this rank sends to rank d      (d = 0..world-1, including itself)
+//   counts[world + s]     records this rank receives from rank s (they fill its slots in order)
+// One workgroup; N = L*world <= kPfPlanMax.
+template <int DUMMY = 0>
+__global__ void __launch_bounds__(256) pf_exchange_plan_kernel(const int* __restrict__ keep, int N, int L, int rank, int world,
+                                                                int* __restrict__ send_idx, int* __restrict__ counts)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * world; i += 256)
+    {
+        counts[i] = 0;
+    }
+    // flags, then an exclusive scan (blocked: each thread owns a contiguous run of g)
+    const int per = (N + 255) / 256;
+    const int g0 = tid * per, g1 = min(N, g0 + per);
+    int       cnt = 0;
+    for (int g = g0; g < g1; g++)
+    {
+        cnt += (keep[g] / L == rank) ? 1 : 0;
+    }
+    __shared__ int s_part[257];
+    s_part[tid + 1] = cnt;
+    if (tid == 0)
+    {
+        s_part[0] = 0;
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        for (int i = 1; i <= 256; i++)
+        {
+            s_part[i] += s_part[i - 1];
+        }
+    }
+    __syncthreads();
+    int pos = s_part[tid];
+    for (int g = g0; g < g1; g++)
+    {
+        if (keep[g] / L == rank)
+        {
+            send_idx[pos++] = keep[g] - rank * L;
+            atomicAdd(&counts[g / L], 1);
+        }
+        if (g / L == rank)
+        {
+            atomicAdd(&counts[world + keep[g] / L], 1);
+        }
+    }
+}
+
 // slot i <- particle keep[i] for every row of the SoA store, through a scratch copy in the same layout: both passes
 // read and write along the particle index (coalesced), whereas the record form (pack/unpack: one block per particle)
 // strides by np between consecutive elements.  grid = (rows, ceil(np/256)); PASS 0: tmp <- gather, PASS 1: store <- tmp.

@@ -131,6 +131,42 @@ class TorchComm:
         return out
 
 
+class RcclComm:
+    """The engine's own RCCL communicator (cslam_comm_create, include/cslam.h): the sharded resample then runs entirely
+    behind the C ABI (cslam_pf_resample_sharded) -- all-reduce, all-gather, the keep[] plan on the device and one grouped
+    send/recv -- with no tensor library in the data path.  The 128-byte unique id is created on rank 0 and handed to
+    the other ranks through torch.distributed (any backend; gloo will do), which is used for nothing else."""
+
+    def __init__(self, device: int, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        L = _capi.lib()
+        buf = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            check(L.cslam_comm_unique_id(buf))
+        t = torch.tensor(list(buf), dtype=torch.uint8)
+        backend = dist.get_backend(group)
+        if backend == "nccl":
+            t = t.cuda(device)
+        dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+        self._h = C.c_void_p(None)
+        check(L.cslam_comm_create(C.c_char_p(raw), C.c_int(self.rank), C.c_int(self.world), C.c_int(device),
+                                  C.byref(self._h)))
+        self._L = L
+
+    def all_reduce_sum(self, vals):  # (kept for callers that only want the sums)
+        raise NotImplementedError("RcclComm is used through ParticleShard.resample_sharded")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.cslam_comm_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+
 # ------------------------------------------------------------------------------------------------
 # the shard on the GPU
 # ------------------------------------------------------------------------------------------------
@@ -260,6 +296,16 @@ class ParticleShard:
                                               C.c_int(1 if resample_status else 0), C.byref(neff), C.byref(did)))
         return float(neff.value), bool(did.value)
 
+    def resample_sharded(self, comm: "RcclComm", select, n_effective: float, resample_status: bool):
+        """PF::resampleParticles over the particle set sharded across comm.world ranks, behind the C ABI
+        (cslam_pf_resample_sharded).  select: the world * n_local strata positions, identical on every rank."""
+        select = np.ascontiguousarray(select, dtype=self.dtype)
+        assert select.shape[0] == self.n_local * comm.world
+        neff, did = C.c_double(0.0), C.c_int(0)
+        check(self._L.cslam_pf_resample_sharded(self._h, comm._h, _vp(select), C.c_double(float(n_effective)),
+                                                C.c_int(1 if resample_status else 0), C.byref(neff), C.byref(did)))
+        return float(neff.value), bool(did.value)
+
     def pack_into(self, src_idx: np.ndarray, dptr: int):
         src_idx = np.ascontiguousarray(src_idx, dtype=np.int32)
         check(self._L.cslam_pf_pack(self._h, _vp(src_idx), C.c_int(src_idx.shape[0]), C.c_void_p(dptr)))
@@ -331,6 +377,12 @@ def resample_particles(shard, comm, n_effective: int, resample_status: bool, sel
             assert uniforms is not None, "pass select[] or the uniform draws it is built from"
             select = stratified_random(n, uniforms, shard.dtype)
         return shard.resample_local(np.asarray(select, dtype=shard.dtype), n_effective, resample_status)
+    if isinstance(comm, RcclComm):
+        # sharded over GPUs: the three collectives, the plan and the moves all run behind the C ABI on the device
+        if select is None:
+            assert uniforms is not None, "pass select[] or the uniform draws it is built from"
+            select = stratified_random(n, uniforms, shard.dtype)
+        return shard.resample_sharded(comm, select, n_effective, resample_status)
     s1, s2 = shard.weight_sums()
     ws, ws2 = comm.all_reduce_sum([s1, s2])          # collective 1: two scalars
     shard.scale_weights(1.0 / ws)                     # PF.cpp:482-487

@@ -111,7 +111,9 @@ int cslam_ekf_update_device(cslam_ekf_t h, const void* dZ, int m, const void* R,
 int cslam_ekf_augment(cslam_ekf_t h, const void* Z, int q, const void* R);
 
 /* Replaces Slam::observeHeading(X, P, phi, useHeading)  -- slam.h:788, EKF.cpp:328-352 with
- * josephUpdate slam.h:700-725 (evaluated in its exact rank-structured O(n^2) form). */
+ * josephUpdate slam.h:700-725.  With H = e_2^T the Joseph form equals P - p p^T / S (p = P[:,2], S = P22 + R) for a
+ * symmetric P: the pose stripe is updated at once, the map block receives the rank-1 downdate as one more pending
+ * column of the next P-GEMM.  O(n); a predict() issued just before it runs in the same launch. */
 int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading);
 
 /* Gated nearest-neighbour data association: Slam::dataAssociate (slam.h, implemented at EKF.cpp:235-326 with
@@ -130,13 +132,30 @@ int cslam_ekf_associate(cslam_ekf_t h, const void* Z, int m, const void* R, doub
  * P-GEMM (k = pending columns): every reader of P adds the rank-k correction for the columns it touches, so
  * results are the reference's up to rounding.  0 (default) applies each update's downdate at once.  The
  * sequential form update(batch = 0) always defers its m rank-2 downdates to one pass at the end of the call
- * (SURVEY.md 8f rank 2).  get_state / trace / observe_heading / flush apply whatever is pending. */
+ * (SURVEY.md 8f rank 2).  get_state / trace / associate / flush apply whatever is pending.
+ * The default f32 engine is PIPELINED (two streams): the W1 panel of the last update is always pending and its P-GEMM
+ * runs on the second stream underneath the next update's factor / gain chain; set_deferred widens that window. */
 int cslam_ekf_set_deferred(cslam_ekf_t h, int max_pending_columns);
 int cslam_ekf_flush(cslam_ekf_t h);
 
-/* Per-stage device times of update() measured with HIP events on the handle's stream.
+/* The two HIP streams (hipStream_t) of a handle: the chain stream carries everything except the covariance downdate,
+ * the P-GEMM stream carries P -= W1*W1^T of the previous update (the same stream when the engine is not pipelined).
+ * For callers that want to order their own work (event records, input copies) against the engine's. */
+int cslam_ekf_get_streams(cslam_ekf_t h, void** chain_stream, void** pgemm_stream);
+
+/* Monte-Carlo driver (BASELINE configs[4]; the reference's unit is one filter loop, test/main.cpp:132-200): runs
+ * `steps` x { predict(v[t], swa[t], Q, wb, dt); update(Z_t, R, idf_t, batch) } on each of `count` INDEPENDENT filter
+ * handles at once, one host thread and one stream pair per handle.  dZ[i] / d_idf[i]: device-resident inputs of
+ * instance i, steps x (2*m scalars) and steps x (m ints), step-major.  Returns when every instance has been enqueued
+ * (asynchronous mode) or has finished (sync mode); cslam_ekf_synchronize waits for an instance. */
+int cslam_ekf_run_many(cslam_ekf_t* handles, int count, int steps, const double* v, const double* swa, const void* Q,
+                       double wb, double dt, const void* const* dZ, const int* const* d_idf, int m, const void* R,
+                       int batch);
+
+/* Per-stage device times of update() measured with HIP events on the handle's streams.
  * on = 1 starts recording (events around every stage of every update), on = 2 brackets the covariance downdate
- * (P-GEMM) launches only, on = 3 one downdate launch in sixteen (an event pair costs ~11 us of stream time), on = 0 stops.
+ * (P-GEMM) launches only, on = 3 one downdate launch in sixteen, on = 4 one in four (an event pair costs ~11 us of
+ * stream time), on = 0 stops.
  * get: synchronises, writes the SUM of milliseconds per stage since profiling was switched on and the
  * number of launches per stage. */
 int cslam_ekf_set_profiling(cslam_ekf_t h, int on);
@@ -210,6 +229,27 @@ int cslam_pf_unpack(cslam_pf_t h, const int* dst_idx, int count, const void* d_r
 int cslam_pf_resample_local(cslam_pf_t h, const void* select, double n_effective, int resample_status, double* neff,
                             int* resampled);
 int cslam_pf_gather_local(cslam_pf_t h, const int* keep, double w_new);
+
+/* ---- the resample step over a particle set SHARDED across GPUs, one process (rank) per GPU:
+ * PF::resampleParticles (slam.h:871-872, PF.cpp:473-500) with stratifiedResample (PF.cpp:546-574) where every rank
+ * holds n_particles of the world * n_particles particles (block partition: global slot g lives on rank g / n_particles).
+ * The collectives run over RCCL (xGMI inside a node) on the handle's stream:
+ *     1. all-reduce(sum) of [sum w, sum w^2]                       -> normalisation and Neff, identical on every rank
+ *     2. only when it resamples: all-gather of the normalised weights; every rank derives the identical keep[] on its
+ *        own device from the shared strata positions
+ *     3. one grouped send/recv of the packed particle records whose source rank differs from the destination rank
+ * `select`: the world * n_particles strata positions of PF.cpp:557 (host pointer), identical on every rank.
+ * neff / resampled may be NULL.  The librccl of the process is bound at run time (dlopen): there is no link-time
+ * dependency, and a process that never shards never loads it.
+ * A communicator is made the RCCL way: rank 0 calls cslam_comm_unique_id, distributes the CSLAM_COMM_ID_BYTES bytes by
+ * whatever means the application has (MPI_Bcast, a file, torch.distributed), every rank calls cslam_comm_create. */
+typedef struct cslam_comm* cslam_comm_t;
+#define CSLAM_COMM_ID_BYTES 128
+int cslam_comm_unique_id(void* id_bytes);
+int cslam_comm_create(const void* id_bytes, int rank, int world, int device, cslam_comm_t* out);
+int cslam_comm_destroy(cslam_comm_t c);
+int cslam_pf_resample_sharded(cslam_pf_t h, cslam_comm_t comm, const void* select, double n_effective,
+                              int resample_status, double* neff, int* resampled);
 /* download one particle (host buffers; any may be NULL): w (1), Xv (3), Pv (9), XF (2*nf), PF (4*nf) */
 int cslam_pf_get_particle(cslam_pf_t h, int index, void* w, void* Xv, void* Pv, void* XF, void* PF);
 /* upload one particle with nf features (nf must equal the current feature count, or set it when the

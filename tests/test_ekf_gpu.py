@@ -583,9 +583,11 @@ def test_predict_fused_into_the_update_kernels(gpu_required, quirks, monkeypatch
     X, P = make_scenario(N, dtype, seed=91, corr=0.3)
     Q = np.diag([0.18, 6e-4]).astype(dtype)
     R = np.diag([0.08, 0.0024]).astype(dtype)
+    monkeypatch.setenv("CSLAM_PIPELINE", "0")  # the fused form belongs to the single-stream engine
     fused = _engine(N, dtype, quirks, X, P)
+    monkeypatch.delenv("CSLAM_PIPELINE")
     monkeypatch.setenv("CSLAM_FUSE_PREDICT", "0")
-    plain = _engine(N, dtype, quirks, X, P)
+    plain = _engine(N, dtype, quirks, X, P)           # two-stream pipelined engine, every predict launched on its own
     monkeypatch.delenv("CSLAM_FUSE_PREDICT")
     orc = OracleState(X, P, dtype, quirks, 0)
     hi = OracleState(X.astype(np.float64), P.astype(np.float64), np.float64, quirks, 0)
@@ -616,3 +618,73 @@ def test_predict_fused_into_the_update_kernels(gpu_required, quirks, monkeypatch
     assert_close("P", Pf, orc.p(), 4 * P_RTOL[dt], hi.p(), fair=8.0)
     fused.close()
     plain.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", QUIRKS)
+def test_reference_loop_cadence(gpu_required, dtype, quirks):
+    """The cadence of the reference's driver (test/main.cpp:132-200): predict + observeHeading on every control step,
+    update + augment every 6th.  The heading observation is a rank-1 pending column here (ekf_pose_kernels.hpp) and the
+    update's P-GEMM runs under the next steps -- against the oracle's dense loop, three observation cycles."""
+    N, m, extra = 140, 9, 3
+    eng, orc, hi = _pair(N, dtype, quirks, seed=321, extra=extra, corr=0.1)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    rng = np.random.default_rng(17)
+    nf, t = N, 0
+    for cycle in range(3):
+        for sub in range(6):
+            args = (83.33, 0.04 * np.sin(0.3 * t), Q, 73.0, 0.01)
+            phi_obs = float(hi.x()[2]) + 1e-4 * rng.normal()   # a heading measurement near the (f64) estimate
+            for s in (eng, orc, hi):
+                s.predict(*args)
+                s.observe_heading(phi_obs, True)
+            t += 1
+        idf = (rng.permutation(nf)[:m] + 1).astype(np.int32)
+        Z = make_obs(orc.x(), idf, dtype, seed=cycle)
+        Zn = np.array([[250.0 + 40 * cycle], [0.5 - 0.4 * cycle]], dtype=dtype)
+        for s in (eng, orc):
+            s.update(Z, R, idf, True)
+            s.augment(Zn, R)
+        hi.update(Z.astype(np.float64), R.astype(np.float64), idf, True)
+        hi.augment(Zn.astype(np.float64), R.astype(np.float64))
+        nf += 1
+        if cycle == 1:
+            xa = eng.get_x()      # a state read in the middle (X only: nothing is flushed)
+            assert_close("X mid-run", xa, orc.x(), 4 * X_RTOL[np.dtype(dtype)], hi.x(), fair=8.0)
+    X, P = eng.get_state()
+    dt = np.dtype(dtype)
+    assert eng.n == orc.n
+    assert_close("loop X", X, orc.x(), 4 * X_RTOL[dt], hi.x(), fair=8.0)
+    assert_close("loop P", P, orc.p(), 4 * P_RTOL[dt], hi.p(), fair=8.0)
+    eng.close()
+
+
+def test_pipelined_and_single_stream_engines_agree(gpu_required, monkeypatch):
+    """The two-stream pipelined engine (P-GEMM of update t under the chain of update t+1) against the single-stream
+    immediate engine on the same inputs at N = 1000: same answers up to the rounding of the pending-panel correction."""
+    from conan_slam_amd import EKF
+    from conan_slam_amd.synth import Workload
+
+    w = Workload(1000, 24, np.float32)
+    a = EKF(1000, dtype=np.float32, quirks=TEXTBOOK, sync_mode=False)
+    monkeypatch.setenv("CSLAM_PIPELINE", "0")
+    b = EKF(1000, dtype=np.float32, quirks=TEXTBOOK, sync_mode=False)
+    monkeypatch.delenv("CSLAM_PIPELINE")
+    for e in (a, b):
+        e.set_state(w.X0, w.P0)
+    for t in range(10):
+        v, swa = w.controls(t)
+        Z, idf = w.observations(t)
+        for e in (a, b):
+            e.predict(v, swa, w.QE, w.wb, w.dt)
+            if t % 3 == 0:
+                e.observe_heading(0.01 * t, True)
+            e.update(Z, w.RE, idf, batch=True)
+    Xa, Pa = a.get_state()
+    Xb, Pb = b.get_state()
+    assert a.factor_status() == 0 and b.factor_status() == 0
+    assert_close("X", Xa, Xb, 2e-5)
+    assert_close("P", Pa, Pb, 2e-4)
+    a.close()
+    b.close()

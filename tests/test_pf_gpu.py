@@ -239,3 +239,45 @@ def test_device_resample_equals_the_host_planned_one(gpu_required, dtype):
     assert np.array_equal(a.get_weights(), b.get_weights())
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sharded_resample_behind_the_c_abi_world_of_one(gpu_required, dtype):
+    """cslam_pf_resample_sharded (RCCL all-reduce + all-gather, keep[] and the exchange plan on the device, grouped
+    send/recv, include/cslam.h) with a communicator of ONE rank -- all a one-GPU box can host -- against
+    cslam_pf_resample_local: same particles in the same slots bit for bit, same Neff, same decision."""
+    import ctypes as C
+
+    from conan_slam_amd import _capi
+    from conan_slam_amd.pf import SingleComm, resample_particles, stratified_random
+
+    L = _capi.lib()
+    ident = (C.c_ubyte * 128)()
+    _capi.check(L.cslam_comm_unique_id(ident))
+    comm = C.c_void_p(None)
+    _capi.check(L.cslam_comm_create(ident, C.c_int(0), C.c_int(1), C.c_int(-1), C.byref(comm)))
+
+    class OneRank:  # the shape resample_sharded expects of a communicator object
+        _h, world, rank = comm, 1, 0
+
+    npart, nf = 384, 7
+    parts = _random_particles(npart, nf, dtype, seed=51)
+    rng = np.random.default_rng(52)
+    for force in (True, False):
+        w = rng.uniform(0.0, 1.0, npart) ** (5 if force else 0.05)
+        for p, wi in zip(parts, w):
+            p[0] = dtype(wi)
+        a = _shard_from(parts, nf, dtype)
+        b = _shard_from(parts, nf, dtype)
+        select = stratified_random(npart, rng.uniform(size=npart), dtype)
+        ra = a.resample_sharded(OneRank, select, int(0.75 * npart), True)
+        rb = resample_particles(b, SingleComm(), int(0.75 * npart), True, select=select)
+        assert ra[1] == rb[1] == force
+        assert abs(ra[0] - rb[0]) <= 1e-9 * abs(rb[0])
+        assert np.array_equal(a.get_weights(), b.get_weights())
+        for i in range(0, npart, 29):
+            for x, y in zip(a.get_particle(i), b.get_particle(i)):
+                assert np.array_equal(np.asarray(x), np.asarray(y)), (force, i)
+        a.close()
+        b.close()
+    _capi.check(L.cslam_comm_destroy(comm))
