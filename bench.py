@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--defer", type=int, default=0,
                     help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = engine default)")
     ap.add_argument("--instances", type=int, default=8, help="mc: filter instances per GPU")
+    ap.add_argument("--pgemm-wgs", type=int, default=-1,
+                    help="mc: cap on each instance's persistent P-GEMM grid (-1: 512 / instances, 0: whole chip)")
     ap.add_argument("--particles", type=int, default=512)
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--pf-obs", type=int, default=8)
@@ -370,8 +372,7 @@ def ekf_main(args):
             "landmarks": N, "n": n, "obs_per_update": m, "k": k, "gain_algebra": args.quirks,
             "deferred_columns": args.defer,
             "engine": "two-stream pipelined (P-GEMM of update t under the chain of update t+1)"
-                      if (args.dtype == "f32" and storage == "lower" and os.environ.get("CSLAM_PIPELINE", "1") != "0")
-                      else "single stream",
+                      if os.environ.get("CSLAM_PIPELINE", "0") != "0" else "single stream",
             "parallelism": f"replicas x{world} (no collective)",
             "baseline_config": "BASELINE.json configs[2]" if (N, args.dtype) == (5000, "f32") else
                                ("BASELINE.json configs[1]" if (N, args.dtype) == (1000, "f64") else "custom"),
@@ -532,6 +533,7 @@ def mc_main(args):
         w = Workload(N, m, dtype, seed=100 + rank * I + i)
         e = EKF(N, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
         e.set_state(w.X0, w.P0)
+        e.set_pgemm_workgroups(max(32, 512 // I) if args.pgemm_wgs < 0 else args.pgemm_wgs)
         w.P0 = None
         inp = DeviceInputs(torch, w, 2 * total)
         engs.append(e)
@@ -586,7 +588,8 @@ def mc_main(args):
         if dist is not None:
             dist.destroy_process_group()
         return
-    # the same number of steps on ONE instance alone (the filter simply continues)
+    # the same number of steps on ONE instance alone with the whole chip (the filter simply continues)
+    engs[0].set_pgemm_workgroups(0)
     run([0], total, args.warmup)
     sync([0])
     t1 = time.perf_counter()

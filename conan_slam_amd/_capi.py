@@ -59,14 +59,9 @@ def _preload_shared_hip_runtime():
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
             hip_runtime_path = cand
-            # the same goes for RCCL (cslam_pf_resample_sharded binds it with dlopen by SONAME): torch's copy first, so
-            # that torch.distributed and the engine share one
-            rc = os.path.join(libdir, "librccl.so")
-            if os.path.exists(rc) and os.environ.get("CSLAM_PRELOAD_RCCL", "1") != "0":
-                try:
-                    C.CDLL(rc, mode=C.RTLD_GLOBAL)
-                except OSError:
-                    pass
+            # (RCCL, used by cslam_pf_resample_sharded, is bound by the engine with dlopen("librccl.so.1"): a process
+            # that has imported torch gets torch's copy by SONAME, any other process the system one.  It must NOT be
+            # preloaded here: loading torch's librccl ahead of `import torch` ends in a double free at exit.)
     except Exception:
         pass  # fall back to the system runtime
 

@@ -55,6 +55,7 @@ struct EkfBase
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     int         pipeline      = 0; // P-GEMM of update t on stream B under the chain of update t+1 (env CSLAM_PIPELINE)
     int         pgemm_spare   = 16; // pipelined: workgroups the persistent P-GEMM grid leaves out (env CSLAM_PGEMM_SPARE)
+    int         pgemm_wgs     = 0;  // > 0: cap on the persistent P-GEMM grid (cslam_ekf_set_pgemm_workgroups: co-running instances)
     hipStream_t stream   = nullptr; // A: everything except the P-GEMM
     hipStream_t stream_b = nullptr; // B: the P-GEMM (== stream when not pipelined)
 
@@ -108,6 +109,8 @@ struct Ekf : EkfBase
     T*   dSub  = nullptr; // (3 + 64) x 64 compact block of PHT (see ekf_gather_kernel)
     T*   dL    = nullptr; // solve mode: the factor L (64 x 64) and 1/diag(L) (64) of the last update
     T*   dRdiag = nullptr;
+    T*   dM    = nullptr; // 3 x 64: M = G G^T PHT[0:3,:]^T from ekf_factor_mfma_f32 (pose-stripe downdate in the gain kernel)
+    bool m_valid = false; // the last factor launch produced dM
     bool solve_gain = false; // the last factor launch published L instead of G (ekf_gain_solve_f32 follows)
     bool g_from_gt  = false; // the last factor launch wrote only G^T (ekf_factor_mfma_f32): debug transposes it
     int  solve_K    = 0;
@@ -233,6 +236,8 @@ struct Ekf : EkfBase
         (void)hipFree(dSub);
         (void)hipFree(dL);
         (void)hipFree(dRdiag);
+        (void)hipFree(dM);
+        dM = nullptr;
         (void)hipFree(dGt);
         (void)hipFree(dV);
         (void)hipFree(dt_);
@@ -282,8 +287,8 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMemsetAsync(dP, 0, pbytes, stream));
         CSLAM_HIP_TRY(hipMalloc(&dPv, (size_t)3 * ldp * sizeof(T)));
         CSLAM_HIP_TRY(hipMemsetAsync(dPv, 0, (size_t)3 * ldp * sizeof(T), stream));
-        CSLAM_HIP_TRY(hipMalloc(&dPoseDone, 2 * sizeof(int)));
-        CSLAM_HIP_TRY(hipMemsetAsync(dPoseDone, 0, 2 * sizeof(int), stream));
+        CSLAM_HIP_TRY(hipMalloc(&dPoseDone, 4 * sizeof(int)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPoseDone, 0, 4 * sizeof(int), stream));
         CSLAM_HIP_TRY(hipMalloc(&dFlags, 2 * sizeof(int)));
         CSLAM_HIP_TRY(hipMemsetAsync(dFlags, 0, 2 * sizeof(int), stream));
         CSLAM_HIP_TRY(hipHostMalloc(&hFlags, 2 * sizeof(int), hipHostMallocDefault));
@@ -366,6 +371,7 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipMalloc(&dSub, (size_t)(3 + 64) * 64 * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dL, (size_t)64 * 64 * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dRdiag, (size_t)64 * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dM, (size_t)3 * 64 * sizeof(T)));
         }
         CSLAM_HIP_TRY(hipMalloc(&dGt, kk));
         CSLAM_HIP_TRY(hipMalloc(&dScrS, kk));
@@ -461,18 +467,24 @@ struct Ekf : EkfBase
     // ordered behind everything enqueued on stream A so far; the pending store moves on to the other region
     int flush()
     {
+        int rc = launch_pose_queue(); // queued heading steps write pending columns of this region
+        if (rc)
+        {
+            return rc;
+        }
         if (kp == 0)
         {
             return CSLAM_OK;
         }
-        int rc = use_device();
-        if (rc)
+        if ((rc = use_device()))
         {
             return rc;
         }
         T*        W   = wbase(wcur);
         const int kp8 = round_up(kp, 8);
-        if (kp8 > kp) // the LDS-DMA P-GEMM reads W1 in blocks of 8 columns
+        // (the shipped f32 P-GEMM bounds its W1 buffer resource at kp columns: the hardware returns zeros beyond, no
+        // padding needed; the other kernels read whole blocks of 8 columns)
+        if (kp8 > kp && !psym4_takes(kp8))
         {
             CSLAM_HIP_TRY(hipMemset2DAsync(W + (size_t)kp * ldp, (size_t)ldp * sizeof(T), 0,
                                            (size_t)round_up(n, kTile) * sizeof(T), (size_t)(kp8 - kp), stream));
@@ -508,12 +520,18 @@ struct Ekf : EkfBase
         }
         if (hd_cols[wcur] > 0) // its column signs belong to columns that have been applied
         {
-            CSLAM_HIP_TRY(hipMemsetAsync(dSign + (size_t)wcur * wcap, 0, (size_t)wcap * sizeof(int), stream));
-            CSLAM_HIP_TRY(hipMemsetAsync(dSign + (size_t)2 * wcap + wcur, 0, sizeof(int), stream));
+            if (stream_b != stream) // (single stream: ekf_negcol_fix_kernel clears them itself when it had work)
+            {
+                CSLAM_HIP_TRY(hipMemsetAsync(dSign + (size_t)wcur * wcap, 0, (size_t)wcap * sizeof(int), stream));
+                CSLAM_HIP_TRY(hipMemsetAsync(dSign + (size_t)2 * wcap + wcur, 0, sizeof(int), stream));
+            }
             hd_cols[wcur] = 0;
         }
         return CSLAM_OK;
     }
+
+    // k8 columns go through ekf_downdate_psym4_f32 (see launch_downdate)
+    bool psym4_takes(int k8) const { return sizeof(T) == 4 && k8 <= 128 && lower && tune_downdate == 0 && ldp < 32768; }
 
     int launch_negcol_fix(T* W, int kcols, hipStream_t st)
     {
@@ -526,7 +544,7 @@ struct Ekf : EkfBase
         const int nt = lower ? n_sym_tiles : tiles * tiles;
         hipLaunchKernelGGL(ekf_negcol_fix_kernel<T>, dim3(std::min(nt, 2 * num_cus)), dim3(256), 0, st, dP, ldp, n, W, ldp,
                            kcols, dSign + (size_t)wcur * wcap, dSign + (size_t)2 * wcap + wcur,
-                           lower ? dTiles : (const int2*)nullptr, nt, tiles);
+                           lower ? dTiles : (const int2*)nullptr, nt, tiles, dPoseDone + 2, (stream_b == stream) ? 1 : 0);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -852,15 +870,18 @@ struct Ekf : EkfBase
     }
 
     // ---------------------------------------------------------------- predict (EKF.cpp:406-455) / heading (EKF.cpp:328-352)
-    // A predict() is accepted and held back until the next call shows what it can ride with:
-    //   observe_heading()  -> ONE ekf_pose_step_kernel launch does both (the reference's driver calls them back to back
-    //                         on every control step, test/main.cpp:165-168);
-    //   a batch update on the non-pipelined fast path (f32, 16 < k <= 64, nothing pending) -> its gather / factor / gain
-    //                         kernels apply the predict on the fly and commit it (PredictArgs in ekf_kernels.hpp);
-    //   anything else      -> launched on its own first (resolve_predict).  CSLAM_FUSE_PREDICT=0 launches every predict
-    //                         at once.
-    // Both only touch the pose stripe Pv and X, never Ps: they may run while a P-GEMM sweeps Ps on stream B.
+    // Control steps are accepted and held back until something needs their result:
+    //   predict()          is held in `pp`;
+    //   observe_heading()  joins the held predict into ONE step of the pose queue `seq` (the reference's driver calls
+    //                      the two back to back on every control step, test/main.cpp:165-168); up to kPoseSeqMax steps
+    //                      queue up and run in ONE ekf_pose_step_kernel launch (they only touch the pose stripe Pv, X and
+    //                      the pending store: see ekf_pose_kernels.hpp);
+    //   a batch update on the fast path (f32, 16 < k <= 64) applies a held predict on the fly in its gather / factor /
+    //                      gain kernels and commits it (PredictArgs in ekf_kernels.hpp);
+    //   anything else that reads X or P launches what is queued first (resolve_predict).
+    // CSLAM_FUSE_PREDICT=0 launches every predict / heading at once.
     PredictArgs<T> pp{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
+    PoseSeq<T>     seq{};
     T*             dPred = nullptr; // 16 scalars: factor kernel -> gain kernel (see FactorArgs::pred_out)
     bool           fuse_now = false; // the batch in flight consumes pp
     int            fuse_predict = 1;
@@ -871,8 +892,8 @@ struct Ekf : EkfBase
         {
             return fail(CSLAM_ERR_BAD_ARG, "predict: Q is null");
         }
-        int rc = resolve_predict(); // two predicts in a row: the first one runs now
-        if (rc)
+        int rc = CSLAM_OK;
+        if (pp.valid && (rc = queue_step(pp, HeadingArgs<T>{0, (T)0, (T)0}))) // two predicts in a row
         {
             return rc;
         }
@@ -892,58 +913,73 @@ struct Ekf : EkfBase
 
     void set_fuse_predict(int on) override { fuse_predict = on; }
 
-    // the pending predict and / or a heading observation in one launch
-    int pose_step(const HeadingArgs<T>& hd)
+    // append one control step (predict and / or heading) to the pose queue
+    int queue_step(const PredictArgs<T>& p, const HeadingArgs<T>& hd)
     {
+        int rc = CSLAM_OK;
+        if (seq.count == kPoseSeqMax && (rc = launch_pose_queue()))
+        {
+            return rc;
+        }
+        int col = -1;
+        if (hd.valid && n > 3)
+        {
+            // the rank-1 downdate -p p^T / S of the map block is one more pending column
+            if (kp + 1 > wcap)
+            {
+                if ((rc = launch_pose_queue()) || (rc = flush()))
+                {
+                    return rc;
+                }
+            }
+            if ((rc = own_region(wcur)))
+            {
+                return rc;
+            }
+            col = kp;
+            kp += 1;
+            hd_cols[wcur] += 1;
+        }
+        const int s = seq.count++;
+        seq.pp[s]   = p;
+        seq.hd[s]   = hd;
+        seq.col[s]  = col;
+        if (&p == &pp)
+        {
+            pp.valid = 0;
+        }
+        return CSLAM_OK;
+    }
+
+    int launch_pose_queue()
+    {
+        if (seq.count == 0)
+        {
+            return CSLAM_OK;
+        }
         int rc = use_device();
         if (rc)
         {
             return rc;
         }
-        T* wcol = nullptr;
-        if (hd.valid)
-        {
-            if (n > 3)
-            {
-                // the rank-1 downdate -p p^T / S of the map block is one more pending column
-                if (kp + 1 > wcap && (rc = flush()))
-                {
-                    return rc;
-                }
-                if ((rc = own_region(wcur)))
-                {
-                    return rc;
-                }
-                wcol = wbase(wcur) + (size_t)kp * ldp;
-            }
-            else
-            {
-                wcol = dHead; // no map yet: the column would be all zero
-            }
-        }
-        const int      n_pad = round_up(n, kTile);
-        PredictArgs<T> p0    = pp;
-        pp.valid             = 0;
-        const bool col = hd.valid && n > 3;
-        hipLaunchKernelGGL(ekf_pose_step_kernel<T>, dim3(n_pad / 256 + ((n_pad % 256) ? 1 : 0)), dim3(256), 0, stream, dX, dPv,
-                           ldp, n, n_pad, p0, hd, wcol, col ? dSign + (size_t)wcur * wcap + kp : (int*)nullptr,
-                           dSign + (size_t)2 * wcap + wcur, dPoseDone);
+        const int n_pad = round_up(n, kTile);
+        hipLaunchKernelGGL(ekf_pose_step_kernel<T>, dim3((n_pad + 255) / 256), dim3(256), 0, stream, dX, dPv, ldp, n, n_pad,
+                           seq, wbase(wcur), ldp, dHead, dSign + (size_t)wcur * wcap, dSign + (size_t)2 * wcap + wcur,
+                           dPoseDone);
         CSLAM_HIP_TRY(hipGetLastError());
-        if (col)
-        {
-            kp += 1;
-            hd_cols[wcur] += 1;
-        }
+        seq.count = 0;
         return CSLAM_OK;
     }
 
+    // everything queued (and the held predict) runs now
     int resolve_predict() override
     {
-        if (!pp.valid)
+        int rc = CSLAM_OK;
+        if (pp.valid && (rc = queue_step(pp, HeadingArgs<T>{0, (T)0, (T)0})))
         {
-            return CSLAM_OK;
+            return rc;
         }
-        return pose_step(HeadingArgs<T>{0, (T)0, (T)0});
+        return launch_pose_queue();
     }
 
     // ---------------------------------------------------------------- update
@@ -975,6 +1011,8 @@ struct Ekf : EkfBase
         a.sub      = sub_valid ? dSub : nullptr;
         a.dL       = nullptr;
         a.dRdiag   = nullptr;
+        a.dM       = nullptr;
+        m_valid    = false;
         solve_gain = false;
         g_from_gt  = false;
         a.pp       = fuse_now ? pp : PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
@@ -1043,6 +1081,11 @@ struct Ekf : EkfBase
                         solve_gain = true;
                         solve_K    = (k <= 32) ? 32 : 64;
                     }
+                    if (tune_gain == 0)
+                    {
+                        a.dM    = dM;
+                        m_valid = true;
+                    }
                     if (k <= 32)
                     {
                         hipLaunchKernelGGL((ekf_factor_mfma_f32<32>), dim3(1), dim3(256), 0, stream, a, dU);
@@ -1102,7 +1145,8 @@ struct Ekf : EkfBase
     // of the downdate at once and the panel's pose rows are zeroed (ekf_pose_downdate_kernel)
     int launch_gain(int k, T* slot)
     {
-        const int n_pad = round_up(n, kTile);
+        const int n_pad    = round_up(n, kTile);
+        pose_fused_in_gain = false;
         if (launch_gain_fast(k, n_pad, slot))
         {
             CSLAM_HIP_TRY(hipGetLastError());
@@ -1121,11 +1165,16 @@ struct Ekf : EkfBase
             }
             CSLAM_HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(ekf_pose_downdate_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, stream, slot, ldp, k,
+        if (pose_fused_in_gain)
+        {
+            return CSLAM_OK; // ekf_panel_mfma_f32 applied the pose-stripe downdate and zeroed the panel's pose rows itself
+        }
+        hipLaunchKernelGGL(ekf_pose_downdate_kernel<T>, dim3((n + 63) / 64), dim3(256), 0, stream, slot, ldp, k,
                            round_up(k, 8), n, dPv, ldp, dWv, dPoseDone + 1);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
+    bool pose_fused_in_gain = false;
 
     int  launch_downdate(const T* W, int k, hipStream_t st);
     bool launch_factor_blocked(const FactorArgs<T>& a, int k); // f32, 32 < k <= 64
@@ -1143,10 +1192,12 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        // a pending predict() rides along when this batch takes the (non-pipelined) fast path with nothing else pending
-        fuse_now = pp.valid && sizeof(T) == 4 && !pipeline && !keep_pending && kp == 0 && k > 16 && k <= 64 &&
-                   tune_factor == 0 && tune_gain == 0;
-        if (pp.valid && !fuse_now && (rc = resolve_predict()))
+        // a few pending columns (heading observations) are corrected for inside the gather kernel: the fast path stays
+        const bool small_corr = kp > 0 && kp <= kGatherCorr && !pipeline;
+        // a pending predict() rides along when this batch takes the (non-pipelined) fast path
+        fuse_now = pp.valid && sizeof(T) == 4 && !pipeline && !keep_pending && (kp == 0 || small_corr) && k > 16 &&
+                   k <= 64 && tune_factor == 0 && tune_gain == 0;
+        if ((rc = fuse_now ? launch_pose_queue() : resolve_predict())) // (queued control steps come first either way)
         {
             return rc;
         }
@@ -1183,10 +1234,12 @@ struct Ekf : EkfBase
         }
         const dim3 ggrid((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs);
         // the compact H-rows block for the MFMA factor kernel (f32, 16 < k <= 64, no pending panels to correct)
-        sub_valid = (sizeof(T) == 4 && k > 16 && k <= 64 && kp == 0 && tune_factor == 0 && dSub != nullptr);
+        sub_valid = (sizeof(T) == 4 && k > 16 && k <= 64 && (kp == 0 || small_corr) && tune_factor == 0 && dSub != nullptr);
         PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
         hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, dPv, ldp, n, dZ, dIdf, m, dPHT, ldp,
-                           lower, sub_valid ? dSub : nullptr, fuse_now ? pp : pnone, fuse_now ? dPred : (T*)nullptr);
+                           lower, sub_valid ? dSub : nullptr, fuse_now ? pp : pnone, fuse_now ? dPred : (T*)nullptr,
+                           small_corr ? (const T*)wbase(wcur) : (const T*)nullptr, ldp, small_corr ? kp : 0,
+                           (small_corr && hd_cols[wcur] > 0) ? dSign + (size_t)wcur * wcap : (const int*)nullptr);
         CSLAM_HIP_TRY(hipGetLastError());
         // the panels this update's P*H^T must be corrected with, and where its own W1 goes
         const T*  Wc        = wbase(wcur);
@@ -1204,7 +1257,7 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        if (kc > 0) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T (their pose rows are zero)
+        if (kc > 0 && !small_corr) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T (their pose rows are zero)
         {
             hipLaunchKernelGGL(ekf_pending_y_kernel<T>, dim3(m, (kc + 255) / 256), dim3(256), 0, stream, dX, n, dZ, dIdf, m,
                                Wc, ldp, kc, dY, hd_cols[rc_region] > 0 ? dSign + (size_t)rc_region * wcap : (const int*)nullptr);
@@ -1279,6 +1332,7 @@ struct Ekf : EkfBase
         CSLAM_HIP_TRY(hipMemcpyAsync(dGt, Gt.data(), Gt.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         solve_gain = false; // the fallback gain is a general matrix: apply it with the product kernel
         g_from_gt  = false;
+        m_valid    = false; // (M belonged to the zeroed G: the separate pose downdate kernel runs)
         CSLAM_HIP_TRY(hipMemcpyAsync(dt_, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         std::vector<T> u((size_t)k, (T)0);
         for (int q = 0; q < k; q++)
@@ -1415,7 +1469,7 @@ struct Ekf : EkfBase
         {
             // (pending panels: their rows for the new feature are zero, which is right -- the kernel writes values of
             // the true P, built from the pose stripe)
-            hipLaunchKernelGGL(ekf_augment_kernel<T>, dim3(1), dim3(1024), 0, stream, dX, dP, dPv, ldp, n, Z[2 * i],
+            hipLaunchKernelGGL(ekf_augment_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, stream, dX, dP, dPv, ldp, n, Z[2 * i],
                                Z[2 * i + 1], R[0], R[1], R[2], R[3], lower);
             CSLAM_HIP_TRY(hipGetLastError());
             n += 2;
@@ -1431,8 +1485,13 @@ struct Ekf : EkfBase
             return CSLAM_OK; // EKF.cpp:332-335 (a pending predict stays pending)
         }
         // float sigmaPhi = 0.01F * pi / 180.0F; R = pow(sigmaPhi, 2)
-        T sigma = (T)(((double)0.01f * kPi) / 180.0);
-        return pose_step(HeadingArgs<T>{1, (T)phi, sigma * sigma}); // with the pending predict, if any, in the same launch
+        T   sigma = (T)(((double)0.01f * kPi) / 180.0);
+        int rc    = queue_step(pp, HeadingArgs<T>{1, (T)phi, sigma * sigma}); // with the held predict, if any
+        if (rc || fuse_predict)
+        {
+            return rc;
+        }
+        return launch_pose_queue();
     }
 
     int factor_status(int* flags, int clear) override
@@ -1641,7 +1700,11 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
         // Persistent grid: two workgroups per CU, minus `pgemm_spare` -- a few CUs keep one workgroup (64 of 160 KB LDS)
         // so that the one-workgroup factor kernel of the NEXT update (53 KB LDS, stream A) finds room while this P-GEMM
         // fills the chip (pipelined mode).
-        const int G = std::min(n_sym_tiles, std::max(1, 2 * num_cus - (pipeline ? pgemm_spare : 0)));
+        int G = std::min(n_sym_tiles, std::max(1, 2 * num_cus - (pipeline ? pgemm_spare : 0)));
+        if (pgemm_wgs > 0)
+        {
+            G = std::min(G, pgemm_wgs);
+        }
         if (k8 <= 128 && lower && tune_downdate == 0 && ldp < 32768)
         {
             // every memory operation interleaved with the MFMA loop; two (k <= 64) or four (k <= 128) chunks of 32
@@ -1649,7 +1712,7 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
             const bool nt     = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
             const int  ntmode = psym_nt >= 0 ? psym_nt : (nt ? 1 : 0);
 #define CSLAM_LAUNCH_PSYM4(MODE, NCH)                                                                               \
-    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE, NCH>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8, dTiles,  \
+    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE, NCH>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k, dTiles,   \
                        n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds)
             if (k8 <= 64)
             {
@@ -1660,6 +1723,19 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
                 else if (ntmode == 5) { CSLAM_LAUNCH_PSYM4(5, 2); }
                 else if (ntmode == 6) { CSLAM_LAUNCH_PSYM4(6, 2); }
                 else { CSLAM_LAUNCH_PSYM4(0, 2); }
+            }
+            else if (k8 <= 96) // four chunks of 24
+            {
+                if (ntmode == 1)
+                {
+                    hipLaunchKernelGGL((ekf_downdate_psym4_f32<1, 4, 24>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k, dTiles,
+                                       n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((ekf_downdate_psym4_f32<0, 4, 24>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k, dTiles,
+                                       n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds);
+                }
             }
             else
             {
@@ -1777,7 +1853,9 @@ bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot)
         return false; // du is produced by the tuned factor kernels only
     }
     hipLaunchKernelGGL((ekf_panel_mfma_f32<false, true>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n,
-                       k, k, dGt, k, dU, slot, ldp, dX, fuse_now ? (const float*)dPred : (const float*)nullptr, pp.w, dPv, ldp);
+                       k, k, dGt, k, dU, slot, ldp, dX, fuse_now ? (const float*)dPred : (const float*)nullptr, pp.w, dPv, ldp,
+                       m_valid ? (const float*)dM : (const float*)nullptr, dWv);
+    pose_fused_in_gain = m_valid;
     return true;
 }
 
@@ -1945,8 +2023,11 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
             b->lower = 1;
         }
     }
-    // two-stream pipelining (see the top of this file): default for the f32 block-lower engine
-    b->pipeline = (dtype == CSLAM_F32 && b->lower) ? 1 : 0;
+    // two-stream pipelining (see the top of this file) is an option, not the default: measured at N = 5000, k = 64
+    // (profiles/r02_*): the kernels of update t+1 that touch memory crawl underneath the persistent P-GEMM (its waves
+    // are older and keep ~24 KB of requests in flight each: the pending-panel correction takes 65 us instead of 5.5)
+    // and every cross-stream hand-over costs ~6 us, so the period is 138 us against 112 us on one stream.
+    b->pipeline = 0;
     if (const char* pv = getenv("CSLAM_PIPELINE"))
     {
         b->pipeline = atoi(pv) ? 1 : 0;
@@ -2099,6 +2180,17 @@ int cslam_ekf_observe_heading(cslam_ekf_t h, double phi, int use_heading)
 {
     CSLAM_NEED(h);
     return B(h)->observe_heading(phi, use_heading); // (a pending predict rides in the same launch)
+}
+
+int cslam_ekf_set_pgemm_workgroups(cslam_ekf_t h, int workgroups)
+{
+    CSLAM_NEED(h);
+    if (workgroups < 0)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "set_pgemm_workgroups: negative");
+    }
+    B(h)->pgemm_wgs = workgroups;
+    return CSLAM_OK;
 }
 
 int cslam_ekf_get_streams(cslam_ekf_t h, void** chain_stream, void** pgemm_stream)

@@ -240,6 +240,7 @@ __device__ inline void predict_pvv(const PredictArgs<T>& pp, T phi_old, const T*
 // (EKF.cpp:394-395), which in column-major P are contiguous columns -> fully coalesced reads.
 // grid = (ceil(n/256), ceil(m/kGatherObs)), block = 256.
 // ------------------------------------------------------------------------------------------------
+constexpr int kGatherCorr = 8; // pending columns the gather kernel corrects for by itself
 constexpr int kGatherObs = 1; // measured at N = 5000, m = 32: 11.1 us (8 per block), 10.2 (4), 9.5 (2), 8.7 (1): the kernel is a latency chain, more blocks win
 
 template <typename T>
@@ -250,8 +251,14 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
                                                           T* __restrict__ sub = nullptr,
                                                           PredictArgs<T> pp = PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0,
                                                                                              (T)0, (T)0, (T)0, (T)0, 0},
-                                                          T* __restrict__ pred_out = nullptr)
+                                                          T* __restrict__ pred_out = nullptr,
+                                                          const T* __restrict__ Wc = nullptr, int ldwc = 0, int kc = 0,
+                                                          const int* __restrict__ sgn = nullptr)
 {
+    // Wc / kc (kc <= kGatherCorr): a FEW pending columns (heading observations: rank-1 columns, ekf_pose_step_kernel)
+    // are corrected for right here -- PHT = Ps*H^T - Wc*(H*Wc)^T with H*Wc built per workgroup from the two landmark
+    // rows of Wc (its pose rows are zero) -- so that the update keeps its fast path (compact block, fused predict)
+    // instead of going through the separate correction kernels.
     // pp.valid: a predict() is pending (see PredictArgs): this kernel works on the PREDICTED pose and pose rows of P,
     // formed on the fly from the stored ones (which the gain kernel replaces afterwards); nothing is written to X or P.
     // sub (optional, m <= 32): the (3 + 2m) x 2m block of PHT that S = H*PHT reads -- rows 0,1,2 and the two rows
@@ -285,6 +292,13 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         eb[oo]  = p_get<T>(P, Pv, ldp, il, fxe[oo] + 1, lower);
     }
     T p0 = Pv[(size_t)0 * ldp + il], p1 = Pv[(size_t)1 * ldp + il], p2 = Pv[(size_t)2 * ldp + il];
+    T wc[kGatherCorr];
+#pragma unroll
+    for (int q = 0; q < kGatherCorr; q++)
+    {
+        wc[q] = (q < kc) ? Wc[(size_t)q * ldwc + il] : (T)0;
+    }
+    __shared__ T s_y[kGatherObs][2][kGatherCorr];
     if (pp.valid && i < 3)
     {
         for (int cc = 0; cc < 3; cc++)
@@ -329,6 +343,32 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         }
     }
     __syncthreads();
+    if (kc > 0) // (workgroup-uniform)
+    {
+        // Y = H*Wc for this workgroup's observations: only the landmark columns of H meet non-zero rows of Wc
+        if ((int)threadIdx.x < no * kGatherCorr)
+        {
+            const int oo = threadIdx.x / kGatherCorr, q = threadIdx.x % kGatherCorr;
+            T         y0 = (T)0, y1 = (T)0;
+            if (q < kc)
+            {
+                const T* c  = &s_coef[oo * 10];
+                const T  wa = Wc[(size_t)q * ldwc + s_fx[oo]], wb = Wc[(size_t)q * ldwc + s_fx[oo] + 1];
+                y0          = c[3] * wa;
+                y0 += c[4] * wb;
+                y1 = c[8] * wa;
+                y1 += c[9] * wb;
+                if (sgn != nullptr && sgn[q] != 0)
+                {
+                    y0 = -y0;
+                    y1 = -y1;
+                }
+            }
+            s_y[oo][0][q] = y0;
+            s_y[oo][1][q] = y1;
+        }
+        __syncthreads();
+    }
     if (i >= n)
     {
         return;
@@ -421,6 +461,18 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         s1 += p2 * c[7];
         s1 += a * c[8];
         s1 += b * c[9];
+        if (kc > 0)
+        {
+            T c0 = (T)0, c1 = (T)0;
+#pragma unroll
+            for (int q = 0; q < kGatherCorr; q++)
+            {
+                c0 += wc[q] * s_y[oo][0][q];
+                c1 += wc[q] * s_y[oo][1][q];
+            }
+            s0 -= c0;
+            s1 -= c1;
+        }
         int col = 2 * (o0 + oo);
         PHT[(size_t)col * ldw + i]       = s0;
         PHT[(size_t)(col + 1) * ldw + i] = s1;
@@ -756,6 +808,8 @@ struct FactorArgs
     const T*   sub;    // compact (3+2m) x 2m block of PHT written by ekf_gather_kernel, or nullptr
     T*         dL;     // solve mode (ekf_gain_solve_f32): the factor L (K x K) is published instead of G; or nullptr
     T*         dRdiag; // 1 / diag(L), K values
+    T*         dM;     // optional (ekf_factor_mfma_f32): M = G*(G^T*PHT[0:3,:]^T), 3 x k (row c at dM + c*k): the gain kernel
+                       // then applies the pose-stripe downdate P[:,0:3] -= W1*W1[0:3,:]^T = PHT*M itself (see ekf_panel_mfma_f32)
     PredictArgs<T> pp;   // pending predict (valid = 0: none); honoured by ekf_factor_mfma_f32 only
     const T*   P3;       // P (for Pvv) and its leading dimension, used with pp.valid
     int        ldp3;

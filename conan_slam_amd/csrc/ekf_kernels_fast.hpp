@@ -796,41 +796,47 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
     }
     stamp(9);
     {
-        const int o = tid >> 2, part = tid & 3; // 256 threads = 64 outputs x 4 parts
-        T         s = (T)0;
+        // four right-hand sides at once, 64 threads each: vec 0: t = G^T V, u = G t (slam.h:258-259 regrouped);
+        // vec 1..3: M[:, c] = G (G^T PHT[c, :]^T) for the pose rows c = 0..2 (the rows of `sub`), with which the gain
+        // kernel forms the pose-stripe downdate PHT*M = W1*W1[0:3,:]^T without waiting for W1's pose rows
+        __shared__ T t4[4][K];
+        const int    o = tid & 63, vec = tid >> 6;
+        T            s1 = (T)0;
         if (o < K)
         {
-#pragma unroll 4
-            for (int r = part; r < K; r += 4)
+            const T* vin = (vec == 0) ? V : &sub[(vec - 1) * LD];
+#pragma unroll 8
+            for (int r = 0; r < K; r++)
             {
-                s += Gm[r * gr + o * gc] * V[r]; // padding rows of V are zero
+                const T x = (vec == 0 || r < k) ? vin[r] : (T)0; // padding rows of V are zero; those of sub are stale
+                s1 += Gm[r * gr + o * gc] * x;
             }
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (part == 0 && o < K)
-        {
-            if (o < k)
+            t4[vec][o] = (o < k) ? s1 : (T)0;
+            if (vec == 0 && o < k)
             {
-                a.dt[o] = s;
+                a.dt[o] = s1;
             }
-            tvec[o] = (o < k) ? s : (T)0;
         }
         __syncthreads();
         T s2 = (T)0;
         if (o < K)
         {
-#pragma unroll 4
-            for (int c = part; c < K; c += 4)
+#pragma unroll 8
+            for (int c = 0; c < K; c++)
             {
-                s2 += Gm[o * gr + c * gc] * tvec[c];
+                s2 += Gm[o * gr + c * gc] * t4[vec][c];
             }
-        }
-        s2 += __shfl_xor(s2, 1);
-        s2 += __shfl_xor(s2, 2);
-        if (part == 0 && o < k)
-        {
-            du[o] = s2;
+            if (o < k)
+            {
+                if (vec == 0)
+                {
+                    du[o] = s2;
+                }
+                else if (a.dM != nullptr)
+                {
+                    a.dM[(vec - 1) * k + o] = s2;
+                }
+            }
         }
     }
     stamp(4);
@@ -1688,9 +1694,15 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
                                                           const float* __restrict__ Bt, int ldb,
                                                           const float* __restrict__ u, float* __restrict__ OUT, int ldo,
                                                           float* __restrict__ X, const float* __restrict__ pred = nullptr,
-                                                          int pred_w = 0, float* __restrict__ P = nullptr, int ldp = 0)
+                                                          int pred_w = 0, float* __restrict__ P = nullptr, int ldp = 0,
+                                                          const float* __restrict__ Mv = nullptr,
+                                                          float* __restrict__ wv_out = nullptr)
 {
     // (P here is the pose stripe Pv, see p_get: the predicted stripe and pose block are committed there)
+    // Mv != nullptr (gain, XUPD): the factor kernel supplied M = G G^T PHT[0:3,:]^T (3 x kq): the column-tile-0
+    // workgroups also apply the pose-stripe share of slam.h:260, Pv[:, c] -= PHT * M[c, :]^T (= W1 * W1[c, :]^T), and the
+    // pose rows of the W1 panel are written as ZERO (saved to wv_out, 3 x nc, for the debug entry point): the pending-
+    // panel algebra never touches the stripe.
     // pred != nullptr (gain, XUPD): a predict() was applied on the fly by the gather and factor kernels (PredictArgs);
     // this kernel commits it: the column-tile-0 workgroups write the predicted stripe and Pvv into P and add the state
     // correction to the PREDICTED pose.  pred = {g02, g12, pose (3), Pvv (9)} from the factor kernel.
@@ -1705,7 +1717,7 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
     const int  cc   = cok ? (c0 + lj) : (nc - 1); // clamped: loads are unconditional, the VALUE is selected
     const bool dox  = XUPD && (blockIdx.y == 0);
     f32x16     acc  = {0};
-    float      xs   = 0.f;
+    float      xs   = 0.f, xm0 = 0.f, xm1 = 0.f, xm2 = 0.f;
     const float* pa = A + row0 + lj;
     // SUB: the old values of the output tile are requested first, so that their latency (the tile was written by
     // another kernel on other XCDs a moment ago) hides behind the operand loads and the MFMAs
@@ -1742,6 +1754,19 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
             acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, bb, acc, 0, 0, 0);
             xs += bb * uq[t];
         }
+        if (XUPD && dox && Mv != nullptr) // (workgroup-uniform)
+        {
+#pragma unroll
+            for (int t = 0; t < NP; t++)
+            {
+                const int   q  = qb + 2 * t + lh;
+                const int   qc = (q < kq) ? q : (kq - 1);
+                const float bb = (q < kq) ? b[t] : 0.f;
+                xm0 += bb * Mv[qc];
+                xm1 += bb * Mv[kq + qc];
+                xm2 += bb * Mv[2 * kq + qc];
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; r++)
@@ -1750,39 +1775,77 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
         if (col < nc)
         {
             float* o = OUT + (size_t)col * ldo + row0 + lj;
-            *o       = SUB ? (oldv[r] - acc[r]) : acc[r];
+            if (!SUB && Mv != nullptr && row0 + lj < 3) // pose rows of the W1 panel: kept aside, stored as zero
+            {
+                wv_out[(size_t)(row0 + lj) * nc + col] = acc[r];
+                *o                                     = 0.f;
+            }
+            else
+            {
+                *o = SUB ? (oldv[r] - acc[r]) : acc[r];
+            }
         }
     }
     if (dox)
     {
         xs += __shfl_xor(xs, 32);
+        xm0 += __shfl_xor(xm0, 32);
+        xm1 += __shfl_xor(xm1, 32);
+        xm2 += __shfl_xor(xm2, 32);
         const int r = row0 + lj;
         if (lh == 0 && r < n)
         {
-            if (pred == nullptr)
+            X[r] = ((pred != nullptr && r < 3) ? pred[2 + r] : X[r]) + xs;
+            if (pred != nullptr || Mv != nullptr)
             {
-                X[r] += xs;
-            }
-            else
-            {
-                X[r] = ((r < 3) ? pred[2 + r] : X[r]) + xs;
-                if (r >= 3)
+                // row r of the pose stripe: [predicted (EKF.cpp:439-443)] then [downdated]
+                float a0 = P[(size_t)0 * ldp + r], a1 = P[(size_t)1 * ldp + r], a2 = P[(size_t)2 * ldp + r];
+                if (pred != nullptr)
                 {
-                    if (r - 3 < pred_w) // column r of the cross-covariance stripe (EKF.cpp:442-443), in the pose stripe Pv
+                    if (r >= 3)
                     {
-                        const float a0 = P[(size_t)0 * ldp + r], a1 = P[(size_t)1 * ldp + r], a2 = P[(size_t)2 * ldp + r];
-                        float o0, o1, o2;
-                        predict_stripe_col<float>(pred[0], pred[1], a0, a1, a2, &o0, &o1, &o2);
-                        P[(size_t)0 * ldp + r] = o0;
-                        P[(size_t)1 * ldp + r] = o1;
-                        P[(size_t)2 * ldp + r] = o2;
+                        if (r - 3 < pred_w)
+                        {
+                            float o0, o1, o2;
+                            predict_stripe_col<float>(pred[0], pred[1], a0, a1, a2, &o0, &o1, &o2);
+                            a0 = o0;
+                            a1 = o1;
+                            a2 = o2;
+                        }
+                    }
+                    else // the pose block: predicted Pvv, row r
+                    {
+                        a0 = pred[5 + r];
+                        a1 = pred[5 + r + 3];
+                        a2 = pred[5 + r + 6];
                     }
                 }
-                else if (r == 0)
+                if (r >= 3)
                 {
-                    for (int e = 0; e < 9; e++)
+                    P[(size_t)0 * ldp + r] = a0 - xm0;
+                    P[(size_t)1 * ldp + r] = a1 - xm1;
+                    P[(size_t)2 * ldp + r] = a2 - xm2;
+                }
+                else
+                {
+                    // the 3 x 3 pose block: the increment W1 W1^T is symmetric bit for bit in the reference's product;
+                    // here (r, c) and (c, r) come from different dot products, so the thread of the larger index
+                    // applies ITS increment to both
+                    const float av[3] = {a0, a1, a2};
+                    const float dv[3] = {xm0, xm1, xm2};
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
                     {
-                        P[(size_t)(e / 3) * ldp + (e % 3)] = pred[5 + e];
+                        if (c == r)
+                        {
+                            P[(size_t)c * ldp + r] = av[c] - dv[c];
+                        }
+                        else if (c < r)
+                        {
+                            const float bcr = (pred != nullptr) ? pred[5 + c + 3 * r] : P[(size_t)r * ldp + c]; // (c, r)
+                            P[(size_t)c * ldp + r] = av[c] - dv[c];
+                            P[(size_t)r * ldp + c] = bcr - dv[c];
+                        }
                     }
                 }
             }
@@ -2373,13 +2436,15 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
 //         4 agent-scope (sc1) loads, 5 agent-scope loads and stores, 6 sc1 loads + nt stores (cache-policy experiments)
 // NCH: chunks of 32 columns per tile (2: k <= 64; 4: k <= 128, the deferred flushes).  Chunk c uses LDS buffer pair
 // c & 1; the stores go behind chunk 0, the loads behind chunk 0/1 (NCH = 2) or chunks 1 and 2 (NCH = 4).
-template <int NTMODE, int NCH>
+// KC: columns per chunk (32; 24 with NCH = 4 covers 64 < k <= 96 -- an update's 64 columns plus a few rank-1 heading
+// columns -- at 1.5x instead of 2x the matrix-core work of k = 64, which keeps that launch bandwidth-bound).
+template <int NTMODE, int NCH, int KC = 32>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
                        const int2* __restrict__ tile_list, int ntiles, int* __restrict__ ticket,
                        int* __restrict__ ticket_reset, unsigned long long* __restrict__ hwids)
 {
-    constexpr int KC = 32;
+    static_assert(KC % 8 == 0 && KC / 2 >= ((NCH == 2) ? 16 : 8), "chunk depth: DMA granularity 8, room for the memory-op schedule");
     // four separate LDS objects (not one array): the compiler's wait-count pass can then tell that the panel
     // DMA in flight (other chunk's buffers) does not alias the buffers the MFMA loop is reading
     __shared__ __attribute__((aligned(16))) float s_b0[KC * 128]; // chunk 0: rows of the tile    [kk][128]
@@ -2532,7 +2597,7 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < 16; g++)
+            for (int g = 0; g < KC / 2; g++)
             {
                 mfma_group(std::integral_constant<int, (c & 1)>{}, g);
                 if (c == 0 && g < 8 && !first)

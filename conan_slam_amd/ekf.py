@@ -74,6 +74,10 @@ class EKF:
     def flush(self):
         check(self._L.cslam_ekf_flush(self._h))
 
+    def set_pgemm_workgroups(self, workgroups: int):
+        """Cap the persistent P-GEMM grid (0 = whole chip): for instances that co-run on one GPU."""
+        check(self._L.cslam_ekf_set_pgemm_workgroups(self._h, C.c_int(int(workgroups))))
+
     # ------------------------------------------------------------------ state
     @property
     def n(self) -> int:

@@ -143,6 +143,12 @@ int cslam_ekf_flush(cslam_ekf_t h);
  * For callers that want to order their own work (event records, input copies) against the engine's. */
 int cslam_ekf_get_streams(cslam_ekf_t h, void** chain_stream, void** pgemm_stream);
 
+/* Cap on the workgroups of the persistent covariance-downdate kernel (0 = default: two per compute unit, i.e. the
+ * whole chip).  For several filter instances that run side by side on one GPU (Monte-Carlo runs, one stream each): with
+ * the default every instance's P-GEMM occupies all compute units for its duration and the other instances' small
+ * kernels queue behind it; with e.g. 2 * CUs / instances each instance keeps to its share and their kernels interleave. */
+int cslam_ekf_set_pgemm_workgroups(cslam_ekf_t h, int workgroups);
+
 /* Monte-Carlo driver (BASELINE configs[4]; the reference's unit is one filter loop, test/main.cpp:132-200): runs
  * `steps` x { predict(v[t], swa[t], Q, wb, dt); update(Z_t, R, idf_t, batch) } on each of `count` INDEPENDENT filter
  * handles at once, one host thread and one stream pair per handle.  dZ[i] / d_idf[i]: device-resident inputs of

@@ -667,6 +667,7 @@ def test_pipelined_and_single_stream_engines_agree(gpu_required, monkeypatch):
     from conan_slam_amd.synth import Workload
 
     w = Workload(1000, 24, np.float32)
+    monkeypatch.setenv("CSLAM_PIPELINE", "1")
     a = EKF(1000, dtype=np.float32, quirks=TEXTBOOK, sync_mode=False)
     monkeypatch.setenv("CSLAM_PIPELINE", "0")
     b = EKF(1000, dtype=np.float32, quirks=TEXTBOOK, sync_mode=False)
