@@ -304,6 +304,13 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_par_kernel<T, 128>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
+        else
+        {
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_mfma_f64<64>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_mfma_f64<32>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
         if (getenv("CSLAM_PSYM_STAMPS"))
         {
             CSLAM_HIP_TRY(hipMalloc(&dPsymStamps, 64 * sizeof(long long)));
@@ -1098,6 +1105,29 @@ struct Ekf : EkfBase
                     g_from_gt = true;
                 }
             }
+            if constexpr (std::is_same<T, double>::value)
+            {
+                // the f64 counterpart on v_mfma_f64_16x16x4_f64 (A/B: CSLAM_TUNE_FACTOR=1 selects the readlane kernel)
+                if (k > 16 && tune_factor == 0)
+                {
+                    auto lds64 = [](int K) {
+                        return (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(double) +
+                               (size_t)(K / 2 + 2) * sizeof(int) + 16;
+                    };
+                    a.dM      = dM;
+                    m_valid   = true;
+                    g_from_gt = true;
+                    if (k <= 32)
+                    {
+                        hipLaunchKernelGGL((ekf_factor_mfma_f64<32>), dim3(1), dim3(256), lds64(32), stream, a, dU);
+                    }
+                    else
+                    {
+                        hipLaunchKernelGGL((ekf_factor_mfma_f64<64>), dim3(1), dim3(256), lds64(64), stream, a, dU);
+                    }
+                    launched = true;
+                }
+            }
             // register-resident factorisation with v_readlane broadcasts
             if (launched)
             {
@@ -1234,7 +1264,7 @@ struct Ekf : EkfBase
         }
         const dim3 ggrid((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs);
         // the compact H-rows block for the MFMA factor kernel (f32, 16 < k <= 64, no pending panels to correct)
-        sub_valid = (sizeof(T) == 4 && k > 16 && k <= 64 && (kp == 0 || small_corr) && tune_factor == 0 && dSub != nullptr);
+        sub_valid = (k > 16 && k <= 64 && (kp == 0 || small_corr) && tune_factor == 0 && dSub != nullptr);
         PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
         hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, dPv, ldp, n, dZ, dIdf, m, dPHT, ldp,
                            lower, sub_valid ? dSub : nullptr, fuse_now ? pp : pnone, fuse_now ? dPred : (T*)nullptr,
@@ -1869,9 +1899,12 @@ bool Ekf<float>::launch_corr_fast(int k, const float* Wp, int kc)
 }
 
 template <>
-bool Ekf<double>::launch_corr_fast(int, const double*, int)
+bool Ekf<double>::launch_corr_fast(int k, const double* Wp, int kc)
 {
-    return false;
+    const int n_pad = round_up(n, kTile);
+    hipLaunchKernelGGL((ekf_panel_mfma_f64<true, false>), dim3(n_pad / 16, (k + 15) / 16), dim3(64), 0, stream, Wp, ldp, n, kc,
+                       k, dY, k, nullptr, dPHT, ldp, nullptr);
+    return true;
 }
 
 template <>
@@ -1892,9 +1925,16 @@ bool Ekf<double>::launch_factor_blocked(const FactorArgs<double>&, int)
 }
 
 template <>
-bool Ekf<double>::launch_gain_fast(int, int, double*)
+bool Ekf<double>::launch_gain_fast(int k, int n_pad, double* slot)
 {
-    return false;
+    if (k > 64 || tune_factor != 0) // du (and M) come from the tuned factor kernels
+    {
+        return false;
+    }
+    hipLaunchKernelGGL((ekf_panel_mfma_f64<false, true>), dim3(n_pad / 16, (k + 15) / 16), dim3(64), 0, stream, dPHT, ldp, n, k,
+                       k, dGt, k, dU, slot, ldp, dX, dPv, ldp, m_valid ? (const double*)dM : (const double*)nullptr, dWv);
+    pose_fused_in_gain = m_valid;
+    return true;
 }
 
 template <>
@@ -1902,7 +1942,7 @@ int Ekf<double>::launch_downdate(const double* W, int k, hipStream_t stream)
 {
     const int tiles_r = round_up(n, kTile) / kTile;
     const int tiles_c = round_up(n, kTile) / 64;
-    hipLaunchKernelGGL(ekf_downdate_f64, dim3(tiles_r * tiles_c), dim3(256), 0, stream, dP, ldp, W, ldp, k, tiles_r);
+    hipLaunchKernelGGL(ekf_downdate_f64, dim3(tiles_r * tiles_c), dim3(256), 0, stream, dP, ldp, W, ldp, k, tiles_r, lower);
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -2011,14 +2051,15 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     }
     // Block-lower storage: only 128x128 tiles on/below the tile diagonal of the symmetric P are maintained
     // (the P-GEMM then writes each tile once).  Needs the persistent symmetric kernel -> f32 default path only.
-    b->lower = (dtype == CSLAM_F32 && (b->tune_downdate == 0 || b->tune_downdate == 2 || b->tune_downdate == 3)) ? 1 : 0;
+    b->lower = (dtype == CSLAM_F64 || b->tune_downdate == 0 || b->tune_downdate == 2 || b->tune_downdate == 3) ? 1 : 0;
     if (const char* sv = getenv("CSLAM_STORAGE"))
     {
         if (!strcmp(sv, "full"))
         {
             b->lower = 0;
         }
-        else if (!strcmp(sv, "lower") && dtype == CSLAM_F32 && (b->tune_downdate == 0 || b->tune_downdate == 2 || b->tune_downdate == 3))
+        else if (!strcmp(sv, "lower") &&
+                 (dtype == CSLAM_F64 || b->tune_downdate == 0 || b->tune_downdate == 2 || b->tune_downdate == 3))
         {
             b->lower = 1;
         }

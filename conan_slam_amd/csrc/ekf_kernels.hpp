@@ -1300,9 +1300,16 @@ __global__ void __launch_bounds__(256, 3) ekf_downdate_f32(float* __restrict__ P
 // ------------------------------------------------------------------------------------------------
 constexpr int kDownKC64 = 16;
 
+// lower != 0: block-lower storage (see p_sym): 128 x 64 tiles that lie in 128 x 128 blocks above the block diagonal are
+// not maintained -- their workgroups leave at once, the P-GEMM then reads and writes half of P.
 __global__ void __launch_bounds__(256, 3) ekf_downdate_f64(double* __restrict__ P, int ldp,
-                                                            const double* __restrict__ W1, int ldw, int k, int tiles_r)
+                                                            const double* __restrict__ W1, int ldw, int k, int tiles_r,
+                                                            int lower)
 {
+    if (lower && ((int)(blockIdx.x / tiles_r) >> 1) > (int)(blockIdx.x % tiles_r))
+    {
+        return;
+    }
     __shared__ __attribute__((aligned(16))) double s_pan[kDownKC64 * (128 + 64)];
     double* sB = s_pan;                   // [kc][128] rows
     double* sA = s_pan + kDownKC64 * 128; // [kc][64]  columns

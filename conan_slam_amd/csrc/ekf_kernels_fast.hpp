@@ -852,6 +852,466 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2+K3 (f64) for 16 < k <= 64 on v_mfma_f64_16x16x4_f64: the f64 counterpart of ekf_factor_mfma_f32.
+//
+// The register-resident kernel (ekf_factor_small_kernel<double, 64>) spends 80 k cycles in the factorisation and 44 k
+// in the inverse at k = 64 (two v_readlane per multiplier, 128 KB of straight-line code): 71 of a 119 us step at
+// N = 1000.  Here the matrix lives in the accumulator layout of the f64 MFMA,
+//     tile T[I][J] (16 x 16) = f64x4:  element g of lane l  =  M[16 I + (l>>4) + 4 g][16 J + (l&15)],
+// so row j = 16 J' + jj of a tile sits in register jj>>2 of the 16 lanes with l>>4 == (jj&3), one column per lane:
+// exactly an MFMA operand with the other three k-slots zero (A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]).
+//   Cholesky step j : d = M[j][j] (v_readlane pair), rs = 1/sqrt(d) (v_rsq_f64 + two Newton steps), a = row_j * rs
+//                     (= column j of L, masked to rows >= j) -> LDS; the tiles of block row J' are updated at once
+//                     (one MFMA each, the next pivots need them); the tiles below wait until the 16 columns of the
+//                     block are done and then take them four per MFMA (the operands of steps with different jj&3 occupy
+//                     different k-slots: they simply add).
+//   inverse         : R = I; step q: X[q][:] = R[q][:] * rs_q -> LDS (final orientation of G), R -= L[:, q] X[q][:]
+//                     with the same immediate / deferred split.  200 + 200 MFMAs instead of 2 x 2016 broadcast pairs.
+// Only the upper tiles T[I][J], I <= J, of the symmetric matrix are kept (row j of the upper part = column j of the
+// lower one); R is lower triangular: tiles I >= J.  Same inputs / outputs / flags as ekf_factor_small_kernel; dM is
+// produced as in ekf_factor_mfma_f32.  LDS (dynamic): S | sub (later: the L columns) | small arrays.
+// ------------------------------------------------------------------------------------------------
+__device__ inline double rsqrt_f64(double d)
+{
+    double       y = __builtin_amdgcn_rsq(d); // ~26 bits
+    const double h = 0.5 * d;
+    y              = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+    y              = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+    return y;
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a, double* __restrict__ du)
+{
+    static_assert(K == 32 || K == 64, "two or four 16-wide tiles per dimension");
+    typedef double T;
+    constexpr int  NB = K / 16;
+    constexpr int  LD = K + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f64[];
+    T*   S    = reinterpret_cast<T*>(smem_f64);  // K x LD: S, then G in its final orientation
+    T*   sub  = S + K * LD;                      // (3 + K) x LD: rows of PHT that H touches; then Lm[r + j*LD] = L[r][j]
+    T*   Lm   = sub;
+    T*   coef = sub + (3 + K) * LD;              // (K/2) x 10
+    T*   V    = coef + (K / 2) * 10;             // K
+    T*   rd   = V + K;                           // K: 1 / L[j][j]
+    T*   t4   = rd + K;                          // 4 x K
+    int* fxs  = reinterpret_cast<int*>(t4 + 4 * K); // K/2
+    int* sflg = fxs + K / 2;                     // 2
+    const int k   = 2 * a.m;
+    const int tid = threadIdx.x;
+    auto stamp = [&](int i) {
+        if (a.stamps && tid == 0)
+        {
+            a.stamps[i] = (long long)__builtin_readcyclecounter();
+        }
+    };
+    stamp(0);
+    const T   r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3];
+    if (tid == 0)
+    {
+        sflg[0] = 0;
+        sflg[1] = 0;
+    }
+    if (tid < K)
+    {
+        V[tid] = (T)0;
+    }
+    __syncthreads();
+    // The rows of PHT that H touches -> sub[slot*LD + c]: slots 0..2 = rows 0..2, 3+2o+a = row fx_o + a.  With the
+    // compact block of the gather kernel their loads do not depend on the observation model: they are issued first
+    // and the model (its own dependent loads, sqrt / atan2 in f64) runs while they are in flight.
+    constexpr int NS = ((3 + K) * K + 255) / 256;
+    T             sv[NS];
+    const int     tot = (3 + k) * k;
+    if (a.sub != nullptr)
+    {
+#pragma unroll
+        for (int it = 0; it < NS; it++)
+        {
+            const int e = tid + it * 256;
+            sv[it]      = a.sub[(e < tot) ? e : 0];
+        }
+    }
+    for (int o = tid; o < a.m; o += 256)
+    {
+        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    if (a.sub == nullptr)
+    {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NS; it++)
+        {
+            const int e  = tid + it * 256;
+            const int ec = (e < tot) ? e : 0;
+            const int c = ec / (3 + k), slot = ec - c * (3 + k); // consecutive threads walk down one column of PHT
+            const int row = (slot < 3) ? slot : fxs[(slot - 3) >> 1] + ((slot - 3) & 1);
+            sv[it]        = a.PHT[(size_t)c * a.ldw + row];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NS; it++)
+    {
+        const int e = tid + it * 256;
+        if (e < tot)
+        {
+            int slot, c;
+            if (a.sub != nullptr)
+            {
+                slot = e / k;
+                c    = e - slot * k;
+            }
+            else
+            {
+                c    = e / (3 + k);
+                slot = e - c * (3 + k);
+            }
+            sub[slot * LD + c] = sv[it];
+        }
+    }
+    __syncthreads();
+    stamp(6);
+    // S = H*PHT + RR (slam.h:244): 5-term sums in ascending column order; identity padding
+#pragma unroll
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int r = e & (K - 1), c = e / K;
+        T         v;
+        if (r < k && c < k)
+        {
+            const int ob = r >> 1, ra = r & 1;
+            const T*  cf = &coef[ob * 10 + ra * 5];
+            T         sm = cf[0] * sub[0 * LD + c];
+            sm += cf[1] * sub[1 * LD + c];
+            sm += cf[2] * sub[2 * LD + c];
+            sm += cf[3] * sub[(3 + 2 * ob) * LD + c];
+            sm += cf[4] * sub[(4 + 2 * ob) * LD + c];
+            const int ri = ra + 2 * (c & 1);
+            const T   rv = (ri == 0) ? r00 : ((ri == 1) ? r10 : ((ri == 2) ? r01 : r11));
+            v            = sm + (((c >> 1) == ob) ? rv : (T)0);
+        }
+        else
+        {
+            v = (r == c) ? (T)1 : (T)0;
+        }
+        S[r + c * LD] = v;
+    }
+    __syncthreads();
+    stamp(7);
+    // makeSymmetric (slam.h:776-779): every thread reads (r, c) and (c, r) of its elements, then all write --
+    // (x + y) * 0.5 is the same value from both sides
+    {
+        constexpr int NE = K * K / 256;
+        T             sv[NE];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1), c = e / K;
+            const T   x = S[r + c * LD], y = S[c + r * LD];
+            sv[it]      = (r > c) ? (x + y) * (T)0.5 : ((r < c) ? (y + x) * (T)0.5 : (x + x) * (T)0.5);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1), c = e / K;
+            S[r + c * LD] = sv[it];
+            if (r < k && c < k)
+            {
+                a.dS[r + c * k] = sv[it];
+            }
+        }
+    }
+    // pose rows of PHT (sub rows 0..2) are needed again at the end: park them in t4[1..3] before sub becomes Lm
+    if (tid < 3 * K)
+    {
+        const int c = tid / K, q = tid - c * K;
+        t4[(1 + c) * K + q] = (q < k) ? sub[c * LD + q] : (T)0;
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int lj = lane & 15, lq = lane >> 4;
+    f64x4     Tt[NB][NB]; // upper tiles (I <= J) of S, then (as Rt) lower tiles (I >= J) of the inverse recurrence
+    if (tid < 64)
+    {
+#pragma unroll
+        for (int I = 0; I < NB; I++)
+        {
+#pragma unroll
+            for (int J = I; J < NB; J++)
+            {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                {
+                    Tt[I][J][g] = S[(16 * I + lq + 4 * g) + (16 * J + lj) * LD];
+                }
+            }
+        }
+    }
+    else // the other three waves clear the L-column store (sub is dead)
+    {
+        for (int e = tid - 64; e < K * LD; e += 192)
+        {
+            Lm[e] = (T)0;
+        }
+    }
+    __syncthreads(); // #A: T is in registers, Lm is clear
+    stamp(1);
+    bool failed = false;
+    if (tid < 64)
+    {
+        // ---- Cholesky (right-looking; the matrix stays symmetric, only upper tiles are touched) ----
+#pragma unroll
+        for (int J = 0; J < NB; J++)
+        {
+            T A4[NB][4]; // per block row I > J: the operands of this block's 16 columns, four columns per entry
+#pragma unroll
+            for (int I = 0; I < NB; I++)
+            {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    A4[I][t] = (T)0;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++)
+            {
+                const int j    = 16 * J + jj;
+                const int g    = jj >> 2, slot = jj & 3;
+                const T   dj   = bcast(Tt[J][J][g], 16 * slot + jj);
+                failed         = failed || !(dj > (T)0);
+                const T    rs  = rsqrt_f64(dj);
+                const bool on  = (lq == slot);
+                T          av[NB];
+#pragma unroll
+                for (int Jc = J; Jc < NB; Jc++)
+                {
+                    const bool keep = on && (Jc > J || lj >= jj);
+                    av[Jc]          = keep ? Tt[J][Jc][g] * rs : (T)0; // L[16 Jc + lj][j]
+                    if (on)
+                    {
+                        Lm[(16 * Jc + lj) + j * LD] = av[Jc];
+                    }
+                    if (Jc > J)
+                    {
+                        A4[Jc][g] += av[Jc];
+                    }
+                }
+                if (lane == 0)
+                {
+                    rd[j] = rs;
+                }
+                if (jj < 15) // (after its last column the rows of block J are never read again)
+                {
+#pragma unroll
+                    for (int Jc = J; Jc < NB; Jc++) // block row J: needed by the next pivots
+                    {
+                        Tt[J][Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[J], av[Jc], Tt[J][Jc], 0, 0, 0);
+                    }
+                }
+            }
+            // the tiles below block row J: the block's 16 columns, four per MFMA
+#pragma unroll
+            for (int I = J + 1; I < NB; I++)
+            {
+#pragma unroll
+                for (int Jc = I; Jc < NB; Jc++)
+                {
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                    {
+                        Tt[I][Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(-A4[I][t], A4[Jc][t], Tt[I][Jc], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    else // S is in wave 0's registers: clear it for G (the inverse only writes the non-zero block rows)
+    {
+        for (int e = tid - 64; e < K * LD; e += 192)
+        {
+            S[e] = (T)0;
+        }
+    }
+    __syncthreads(); // #B: L columns and 1/diag are in LDS, S is clear
+    stamp(2);
+    T chk = (T)0;
+    if (tid < 64)
+    {
+        // ---- inv(L): R = I; q ascending: X[q][:] = R[q][:] / L[q][q]; R -= L[:, q] X[q][:] ----
+        // G[r][c]: REF_EXACT G = inv(L) = X, TEXTBOOK G = X^T; S[r + c*LD] = G[r][c]
+        const int sq = a.textbook ? LD : 1, sc = a.textbook ? 1 : LD; // X[q][c] -> S[q*sq + c*sc]
+#pragma unroll
+        for (int I = 0; I < NB; I++)
+        {
+#pragma unroll
+            for (int J = 0; J <= I; J++)
+            {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                {
+                    Tt[I][J][g] = (I == J && (lq + 4 * g) == lj) ? (T)1 : (T)0;
+                }
+            }
+        }
+#pragma unroll
+        for (int Q = 0; Q < NB; Q++)
+        {
+            T X4[NB][4];
+#pragma unroll
+            for (int Jc = 0; Jc < NB; Jc++)
+            {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    X4[Jc][t] = (T)0;
+                }
+            }
+            // the block's 1/diag values and L operands are read up front: the LDS stores of the X rows below would
+            // otherwise fence every read behind them (everything here is carved out of one LDS allocation)
+            T rsv[16], lqv[16];
+#pragma unroll
+            for (int qq = 0; qq < 16; qq++)
+            {
+                rsv[qq] = rd[16 * Q + qq];
+                lqv[qq] = Lm[(16 * Q + lj) + (16 * Q + qq) * LD];
+            }
+#pragma unroll
+            for (int qq = 0; qq < 16; qq++)
+            {
+                const int  q  = 16 * Q + qq;
+                const int  g  = qq >> 2, slot = qq & 3;
+                const bool on = (lq == slot);
+                const T    rs = rsv[qq];
+                const T    lq_ = on ? lqv[qq] : (T)0; // L[16 Q + lj][q] (zero above the diagonal)
+                T          xv[NB];
+#pragma unroll
+                for (int Jc = 0; Jc <= Q; Jc++)
+                {
+                    xv[Jc] = on ? Tt[Q][Jc][g] * rs : (T)0; // X[q][16 Jc + lj]
+                    chk    = __builtin_fma(xv[Jc], (T)0, chk);
+                    if (on)
+                    {
+                        S[q * sq + (16 * Jc + lj) * sc] = xv[Jc];
+                    }
+                    X4[Jc][g] += xv[Jc];
+                }
+                if (qq < 15)
+                {
+#pragma unroll
+                    for (int Jc = 0; Jc <= Q; Jc++)
+                    {
+                        Tt[Q][Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq_, xv[Jc], Tt[Q][Jc], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int I = Q + 1; I < NB; I++)
+            {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    const T li = Lm[(16 * I + lj) + (16 * Q + 4 * t + lq) * LD]; // L[16 I + lj][16 Q + 4 t + lq]
+#pragma unroll
+                    for (int Jc = 0; Jc <= Q; Jc++)
+                    {
+                        Tt[I][Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(-li, X4[Jc][t], Tt[I][Jc], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const bool bad = (__ballot(!(chk == chk)) != 0ull);
+        if (lane == 0)
+        {
+            sflg[0] = failed ? 1 : 0;
+            sflg[1] = (!failed && bad) ? 1 : 0;
+        }
+    }
+    __syncthreads(); // #C
+    stamp(3);
+    stamp(8);
+    const bool zero = (sflg[0] | sflg[1]) != 0;
+    if (zero) // LLT failure (slam.h:421-429 handled by the host in sync mode) or a non-finite inverse: G = 0
+    {
+        for (int e = tid; e < K * LD; e += 256)
+        {
+            S[e] = (T)0;
+        }
+        __syncthreads();
+    }
+    // outputs: G, G^T, then t = G^T V, u = G t and M (see ekf_factor_mfma_f32)
+    // (only G^T is published: it is what the gain kernel reads; the debug entry point transposes it back)
+#pragma unroll
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int c = e & (K - 1), r = e / K;
+        if (r < k && c < k)
+        {
+            a.dGt[c + r * k] = S[r + c * LD];
+        }
+    }
+    stamp(9);
+    {
+        const int o = tid & 63, vec = tid >> 6;
+        T         s1 = (T)0;
+        if (o < K)
+        {
+            const T* vin = (vec == 0) ? V : &t4[vec * K];
+#pragma unroll 16
+            for (int r = 0; r < K; r++)
+            {
+                s1 += S[r + o * LD] * vin[r]; // (G^T x)[o]; padding entries of the inputs are zero
+            }
+        }
+        __syncthreads(); // (t4[1..3] are inputs above and outputs below)
+        if (o < K)
+        {
+            t4[vec * K + o] = (o < k) ? s1 : (T)0;
+            if (vec == 0 && o < k)
+            {
+                a.dt[o] = s1;
+            }
+        }
+        __syncthreads();
+        if (o < K)
+        {
+            T s2 = (T)0;
+#pragma unroll 16
+            for (int c = 0; c < K; c++)
+            {
+                s2 += S[o + c * LD] * t4[vec * K + c]; // (G t)[o]
+            }
+            if (o < k)
+            {
+                if (vec == 0)
+                {
+                    du[o] = s2;
+                }
+                else if (a.dM != nullptr)
+                {
+                    a.dM[(vec - 1) * k + o] = s2;
+                }
+            }
+        }
+    }
+    stamp(4);
+    if (tid == 0)
+    {
+        const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
+        a.flags[1]     = code;
+        if (code)
+        {
+            atomicOr(&a.flags[0], code);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2+K3 for 32 < k <= 64 in f32, blocked 2 x 2 with 32 x 32 blocks:
 //     S = [A11 .; A21 A22]    L11 = chol(A11)            X11 = inv(L11)      (one wave, a row per lane, v_readlane)
 //                             L21 = A21 * X11^T                               (MFMA 32x32x2, operands from LDS)
@@ -1845,6 +2305,145 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f32(const float* __restrict
                             const float bcr = (pred != nullptr) ? pred[5 + c + 3 * r] : P[(size_t)r * ldp + c]; // (c, r)
                             P[(size_t)c * ldp + r] = av[c] - dv[c];
                             P[(size_t)r * ldp + c] = bcr - dv[c];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 (f64) on v_mfma_f64_16x16x4_f64: the f64 counterpart of ekf_panel_mfma_f32 (same generic form, same fusions except
+// the pending predict, which the f64 engine launches on its own).  Tile = 16 rows x 16 columns per single-wave
+// workgroup: D[i][j], i <-> output column (A[i = lane&15][kq = lane>>4] = Bt[(q0+kq)*ldb + c0 + i]), j <-> row
+// (B[kq][j = lane&15] = A[row0 + j][q0 + kq]); element g of a lane is D[(lane>>4) + 4 g][lane&15].
+// grid = (n_pad/16, ceil(nc/16)).  The vector-unit kernel it replaces (ekf_gain_lds_kernel<double>) ran 32 workgroups
+// for 19-25 us at N = 1000, k = 64.
+// ------------------------------------------------------------------------------------------------
+template <bool SUB, bool XUPD>
+__global__ void __launch_bounds__(64) ekf_panel_mfma_f64(const double* __restrict__ A, int lda, int n, int kq, int nc,
+                                                          const double* __restrict__ Bt, int ldb,
+                                                          const double* __restrict__ u, double* __restrict__ OUT, int ldo,
+                                                          double* __restrict__ X, double* __restrict__ Pv = nullptr,
+                                                          int ldp = 0, const double* __restrict__ Mv = nullptr,
+                                                          double* __restrict__ wv_out = nullptr)
+{
+    const int  lane = threadIdx.x;
+    const int  lj   = lane & 15;
+    const int  lq   = lane >> 4;
+    const int  row0 = blockIdx.x * 16;
+    const int  c0   = blockIdx.y * 16;
+    const bool cok  = (c0 + lj) < nc;
+    const int  cc   = cok ? (c0 + lj) : (nc - 1);
+    const bool dox  = XUPD && (blockIdx.y == 0);
+    f64x4      acc  = {0.0, 0.0, 0.0, 0.0};
+    double     xs = 0.0, xm0 = 0.0, xm1 = 0.0, xm2 = 0.0;
+    const double* pa = A + row0 + lj;
+    double oldv[4];
+    if (SUB)
+    {
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            const int col = c0 + lq + 4 * g;
+            oldv[g]       = OUT[(size_t)(col < nc ? col : nc - 1) * ldo + row0 + lj];
+        }
+    }
+    constexpr int NQ = 16; // k-quads per trip: every load of the trip is issued before its first MFMA
+    for (int qb = 0; qb < kq; qb += 4 * NQ)
+    {
+        double b[NQ], g[NQ], uq[NQ], m0[NQ], m1[NQ], m2[NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; t++)
+        {
+            const int q  = qb + 4 * t + lq;
+            const int qc = (q < kq) ? q : (kq - 1);
+            b[t]         = pa[(size_t)qc * lda];
+            g[t]         = Bt[(size_t)qc * ldb + cc];
+            uq[t]        = (XUPD && dox) ? u[qc] : 0.0;
+            if (XUPD && dox && Mv != nullptr)
+            {
+                m0[t] = Mv[qc];
+                m1[t] = Mv[kq + qc];
+                m2[t] = Mv[2 * kq + qc];
+            }
+            else
+            {
+                m0[t] = m1[t] = m2[t] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NQ; t++)
+        {
+            const int    q  = qb + 4 * t + lq;
+            const bool   ok = q < kq;
+            const double gg = (ok && cok) ? g[t] : 0.0;
+            const double bb = ok ? b[t] : 0.0;
+            acc             = __builtin_amdgcn_mfma_f64_16x16x4f64(gg, bb, acc, 0, 0, 0);
+            xs += bb * uq[t];
+            xm0 += bb * m0[t];
+            xm1 += bb * m1[t];
+            xm2 += bb * m2[t];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+    {
+        const int col = c0 + lq + 4 * g;
+        if (col < nc)
+        {
+            double* o = OUT + (size_t)col * ldo + row0 + lj;
+            if (!SUB && Mv != nullptr && row0 + lj < 3) // pose rows of the W1 panel: kept aside, stored as zero
+            {
+                wv_out[(size_t)(row0 + lj) * nc + col] = acc[g];
+                *o                                     = 0.0;
+            }
+            else
+            {
+                *o = SUB ? (oldv[g] - acc[g]) : acc[g];
+            }
+        }
+    }
+    if (dox)
+    {
+        xs += __shfl_xor(xs, 16);
+        xs += __shfl_xor(xs, 32);
+        xm0 += __shfl_xor(xm0, 16);
+        xm0 += __shfl_xor(xm0, 32);
+        xm1 += __shfl_xor(xm1, 16);
+        xm1 += __shfl_xor(xm1, 32);
+        xm2 += __shfl_xor(xm2, 16);
+        xm2 += __shfl_xor(xm2, 32);
+        const int r = row0 + lj;
+        if (lq == 0 && r < n)
+        {
+            X[r] += xs;
+            if (Mv != nullptr)
+            {
+                const double a0 = Pv[(size_t)0 * ldp + r], a1 = Pv[(size_t)1 * ldp + r], a2 = Pv[(size_t)2 * ldp + r];
+                if (r >= 3)
+                {
+                    Pv[(size_t)0 * ldp + r] = a0 - xm0;
+                    Pv[(size_t)1 * ldp + r] = a1 - xm1;
+                    Pv[(size_t)2 * ldp + r] = a2 - xm2;
+                }
+                else // the 3 x 3 pose block: one increment for (r, c) and (c, r) (see ekf_panel_mfma_f32)
+                {
+                    const double av[3] = {a0, a1, a2};
+                    const double dv[3] = {xm0, xm1, xm2};
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                    {
+                        if (c == r)
+                        {
+                            Pv[(size_t)c * ldp + r] = av[c] - dv[c];
+                        }
+                        else if (c < r)
+                        {
+                            const double bcr        = Pv[(size_t)r * ldp + c];
+                            Pv[(size_t)c * ldp + r] = av[c] - dv[c];
+                            Pv[(size_t)r * ldp + c] = bcr - dv[c];
                         }
                     }
                 }
