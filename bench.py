@@ -705,13 +705,21 @@ def pf_main(args):
         inputs.append((w.controls(t), Z, idf, np.ascontiguousarray(nrm), uniform01(900 + t, np.arange(Np, dtype=np.uint64))))
     n_resampled = 0
 
+    from conan_slam_amd.pf import stratified_random
+
+    n_eff_min = Np + 1 if args.force_resample else int(0.75 * Np)
+
     def step(t):
         nonlocal n_resampled
         (v, swa), Z, idf, nrm, u = inputs[t]
+        if world == 1:
+            # one C call, one staged copy, nothing returned (the resample decision stays on the device)
+            sh.observation_step(v, swa, w.QE, w.wb, w.dt, Z, idf, w.RE, nrm, stratified_random(Np, u, dtype), n_eff_min, True)
+            return
         sh.predict(v, swa, w.QE, w.wb, w.dt)
         sh.sample_proposal(Z, idf, w.RE, nrm)
         sh.feature_update(Z, idf, w.RE)
-        neff, did = resample_particles(sh, comm, Np + 1 if args.force_resample else int(0.75 * Np), True, uniforms=u)
+        neff, did = resample_particles(sh, comm, n_eff_min, True, uniforms=u)
         n_resampled += int(did)
 
     for t in range(args.warmup):
@@ -721,6 +729,7 @@ def pf_main(args):
     if dist is not None:
         dist.barrier()
     n_resampled = 0
+    r0 = sh.resample_stats()[1] if world == 1 else 0
     t0 = time.perf_counter()
     for t in range(args.warmup, total):
         step(t)
@@ -730,6 +739,8 @@ def pf_main(args):
     if dist is not None:
         dist.barrier()
     elapsed = max_over_ranks(torch, dist, elapsed)
+    if world == 1:
+        n_resampled = sh.resample_stats()[1] - r0
     ws = sh.get_weights()
     if rank == 0:
         rec_bytes = (13 + 6 * Nf) * 4

@@ -1112,7 +1112,7 @@ struct Ekf : EkfBase
                 {
                     auto lds64 = [](int K) {
                         return (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(double) +
-                               (size_t)(K / 2 + 2) * sizeof(int) + 16;
+                               (size_t)(K / 2 + 4) * sizeof(int) + 16;
                     };
                     a.dM      = dM;
                     m_valid   = true;

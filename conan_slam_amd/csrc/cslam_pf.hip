@@ -127,6 +127,10 @@ struct PfBase
     virtual int gather_local(const int* keep, double w_new)                                   = 0;
     virtual int resample_local(const void* select, double n_eff, int status, double* neff, int* did) = 0;
     virtual int resample_sharded(Comm* c, const void* select, double n_eff, int status, double* neff, int* did) = 0;
+    virtual int observation_step(double v, double swa, const void* Q, double wb, double dt, const void* Z, int m,
+                                 const int* idf, const void* R, const void* normals, const void* select, double n_eff,
+                                 int status) = 0;
+    virtual int resample_stats(double* calls, double* resamples, double* last_neff) = 0;
     virtual int get_particle(int i, void* w, void* Xv, void* Pv, void* XF, void* PF)          = 0;
     virtual int set_particle(int i, const void* w, const void* Xv, const void* Pv, const void* XF, const void* PF,
                              int nf)                                                          = 0;
@@ -272,7 +276,7 @@ struct Pf : PfBase
         dIdx = nullptr;
         mcap = 0;
         staged.clear();
-        CSLAM_HIP_TRY(hipMalloc(&dObs, ((size_t)2 * newm + (size_t)3 * np) * sizeof(T) + (size_t)newm * sizeof(int)));
+        CSLAM_HIP_TRY(hipMalloc(&dObs, ((size_t)2 * newm + (size_t)4 * np) * sizeof(T) + (size_t)newm * sizeof(int)));
         CSLAM_HIP_TRY(hipMalloc(&dIdx, (size_t)std::max(newm, np) * sizeof(int)));
         mcap = newm;
         return CSLAM_OK;
@@ -692,8 +696,9 @@ struct Pf : PfBase
             CSLAM_HIP_TRY(hipMalloc(&dCum, (size_t)np * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dKeep, (size_t)np * sizeof(int)));
             CSLAM_HIP_TRY(hipMalloc(&dEnable, sizeof(int)));
-            CSLAM_HIP_TRY(hipMalloc(&dInfo, 2 * sizeof(double)));
-            CSLAM_HIP_TRY(hipHostMalloc(&hInfo, 2 * sizeof(double), hipHostMallocDefault));
+            CSLAM_HIP_TRY(hipMalloc(&dInfo, 4 * sizeof(double)));
+            CSLAM_HIP_TRY(hipMemsetAsync(dInfo, 0, 4 * sizeof(double), stream));
+            CSLAM_HIP_TRY(hipHostMalloc(&hInfo, 4 * sizeof(double), hipHostMallocDefault));
         }
         char* slot = nullptr;
         if ((rc = stage_slot_for((size_t)np * sizeof(T), &slot)))
@@ -702,15 +707,10 @@ struct Pf : PfBase
         }
         std::memcpy(slot, select, (size_t)np * sizeof(T));
         CSLAM_HIP_TRY(hipMemcpyAsync(dSel, slot, (size_t)np * sizeof(T), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(pf_resample_plan_kernel<T>, dim3(1), dim3(256), 0, stream, dW, np, dSel, n_eff, status, dCum, dKeep,
-                           dInfo, dEnable);
-        CSLAM_HIP_TRY(hipGetLastError());
-        const dim3 ggrid(13 + 6 * store().nf, (np + 255) / 256);
-        const T w_new = (T)(1.0 / (double)np);
-        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 0>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable, w_new);
-        CSLAM_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 1>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable, w_new);
-        CSLAM_HIP_TRY(hipGetLastError());
+        if ((rc = launch_resample(dSel, n_eff, status)))
+        {
+            return rc;
+        }
         if (neff || did)
         {
             CSLAM_HIP_TRY(hipMemcpyAsync(hInfo, dInfo, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -895,6 +895,114 @@ struct Pf : PfBase
         hipLaunchKernelGGL(pf_unpack_kernel<T>, dim3(L), dim3(256), 0, stream, store(), (const int*)nullptr, L, dRecvBuf);
         CSLAM_HIP_TRY(hipGetLastError());
         return set_uniform_weight(1.0 / (double)N); // PF.cpp:495-499
+    }
+
+    // plan (sums, normalise, Neff, decision, keep[]) -> gather -> copy back + w = 1/N, the last two gated by a device flag
+    int launch_resample(const T* d_select, double n_eff, int status)
+    {
+        hipLaunchKernelGGL(pf_resample_plan_kernel<T>, dim3(1), dim3(256), 0, stream, dW, np, d_select, n_eff, status, dCum,
+                           dKeep, dInfo, dEnable);
+        CSLAM_HIP_TRY(hipGetLastError());
+        const dim3 ggrid(13 + 6 * store().nf, (np + 255) / 256);
+        const T    w_new = (T)(1.0 / (double)np);
+        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 0>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable, w_new);
+        CSLAM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 1>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable, w_new);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+
+    int ensure_resample_buffers()
+    {
+        if (!dSel)
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dSel, (size_t)np * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dCum, (size_t)np * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dKeep, (size_t)np * sizeof(int)));
+            CSLAM_HIP_TRY(hipMalloc(&dEnable, sizeof(int)));
+            CSLAM_HIP_TRY(hipMalloc(&dInfo, 4 * sizeof(double)));
+            CSLAM_HIP_TRY(hipMemsetAsync(dInfo, 0, 4 * sizeof(double), stream));
+            CSLAM_HIP_TRY(hipHostMalloc(&hInfo, 4 * sizeof(double), hipHostMallocDefault));
+        }
+        return CSLAM_OK;
+    }
+
+    // One whole FastSLAM-2 observation step for a shard that holds every particle -- predict, sampleProposal,
+    // featureUpdate, resampleParticles (PF.cpp:419-471, 502-544, 222-277, 473-500) -- with ONE staged host-to-device
+    // copy for all its small inputs (Z | idf | normals | select) and nothing returned to the host.
+    int observation_step(double v, double swa, const void* Qv, double wb, double dt, const void* Z, int m, const int* idf,
+                         const void* Rv, const void* normals, const void* select, double n_eff, int status) override
+    {
+        if (!Qv || !Rv || m < 0 || (m > 0 && (!Z || !idf || !normals)) || !select)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_observation_step: bad arguments");
+        }
+        if (np > kPfPlanMax)
+        {
+            return fail(CSLAM_ERR_CAPACITY, "pf_observation_step: %d particles (limit %d)", np, kPfPlanMax);
+        }
+        int rc = use_device();
+        if (rc || (rc = check_idf(idf, m, "pf_observation_step")) || (rc = ensure_m(std::max(m, 1))) ||
+            (rc = ensure_resample_buffers()))
+        {
+            return rc;
+        }
+        const size_t zb = (size_t)2 * m * sizeof(T), ib = (size_t)m * sizeof(int), nb = (size_t)3 * np * sizeof(T);
+        const size_t off_sel = off_normals() + nb, bytes = off_sel + (size_t)np * sizeof(T);
+        char*        slot    = nullptr;
+        if ((rc = stage_slot_for(bytes, &slot)))
+        {
+            return rc;
+        }
+        if (m > 0)
+        {
+            std::memcpy(slot, Z, zb);
+            std::memcpy(slot + off_idf(), idf, ib);
+            std::memcpy(slot + off_normals(), normals, nb);
+        }
+        std::memcpy(slot + off_sel, select, (size_t)np * sizeof(T));
+        staged.clear();
+        CSLAM_HIP_TRY(hipMemcpyAsync(dObs, slot, bytes, hipMemcpyHostToDevice, stream));
+        const T* Q = static_cast<const T*>(Qv);
+        const T* R = static_cast<const T*>(Rv);
+        hipLaunchKernelGGL(pf_predict_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), (T)v, (T)swa, Q[0],
+                           Q[1], Q[2], Q[3], (T)wb, (T)dt);
+        CSLAM_HIP_TRY(hipGetLastError());
+        if (m > 0)
+        {
+            hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(),
+                               m, R[0], R[1], R[2], R[3], dNormals());
+            CSLAM_HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), dObs,
+                               dIdf(), m, R[0], R[1], R[2], R[3], (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1);
+            CSLAM_HIP_TRY(hipGetLastError());
+        }
+        return launch_resample(reinterpret_cast<const T*>(reinterpret_cast<char*>(dObs) + off_sel), n_eff, status);
+    }
+
+    int resample_stats(double* calls, double* resamples, double* last_neff) override
+    {
+        int rc = use_device();
+        if (rc || (rc = ensure_resample_buffers()))
+        {
+            return rc;
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(hInfo, dInfo, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        stage_inflight = 0;
+        if (last_neff)
+        {
+            *last_neff = hInfo[0];
+        }
+        if (calls)
+        {
+            *calls = hInfo[2];
+        }
+        if (resamples)
+        {
+            *resamples = hInfo[3];
+        }
+        return CSLAM_OK;
     }
 
     int get_particle(int i, void* w, void* Xv, void* Pv, void* XF, void* PF) override
@@ -1174,6 +1282,20 @@ int cslam_pf_set_particle(cslam_pf_t h, int index, const void* w, const void* Xv
 {
     CSLAM_NEED(h);
     return B(h)->set_particle(index, w, Xv, Pv, XF, PF, nf);
+}
+
+int cslam_pf_observation_step(cslam_pf_t h, double v, double swa, const void* Q, double wb, double dt, const void* Z, int m,
+                              const int* idf, const void* R, const void* normals, const void* select, double n_effective,
+                              int resample_status)
+{
+    CSLAM_NEED(h);
+    return B(h)->observation_step(v, swa, Q, wb, dt, Z, m, idf, R, normals, select, n_effective, resample_status);
+}
+
+int cslam_pf_resample_stats(cslam_pf_t h, double* calls, double* resamples, double* last_neff)
+{
+    CSLAM_NEED(h);
+    return B(h)->resample_stats(calls, resamples, last_neff);
 }
 
 int cslam_comm_unique_id(void* id_bytes)

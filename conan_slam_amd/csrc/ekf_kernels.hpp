@@ -1302,7 +1302,7 @@ constexpr int kDownKC64 = 16;
 
 // lower != 0: block-lower storage (see p_sym): 128 x 64 tiles that lie in 128 x 128 blocks above the block diagonal are
 // not maintained -- their workgroups leave at once, the P-GEMM then reads and writes half of P.
-__global__ void __launch_bounds__(256, 3) ekf_downdate_f64(double* __restrict__ P, int ldp,
+__global__ void __launch_bounds__(256, 2) ekf_downdate_f64(double* __restrict__ P, int ldp,
                                                             const double* __restrict__ W1, int ldw, int k, int tiles_r,
                                                             int lower)
 {
@@ -1332,6 +1332,21 @@ __global__ void __launch_bounds__(256, 3) ekf_downdate_f64(double* __restrict__ 
         for (int cb = 0; cb < 4; cb++)
         {
             acc[b][cb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    // the P tile is requested before the panels: its latency hides behind the panel loads and the MFMA loop
+    // (it used to be loaded in the epilogue: 22-26 us per launch at N = 1000 although P sits in the L2 / Infinity Cache)
+    double2* ptr[16];
+    double2  v[16];
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++)
+    {
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            const int col   = col0 + cb * 16 + lq + 4 * g;
+            ptr[cb * 4 + g] = reinterpret_cast<double2*>(P + (size_t)col * ldp + row0 + wave * 32 + 2 * lj);
+            v[cb * 4 + g]   = *ptr[cb * 4 + g];
         }
     }
     for (int k0 = 0; k0 < k; k0 += kDownKC64)
@@ -1374,19 +1389,6 @@ __global__ void __launch_bounds__(256, 3) ekf_downdate_f64(double* __restrict__ 
         }
     }
     {
-        double2* ptr[16];
-        double2  v[16];
-#pragma unroll
-        for (int cb = 0; cb < 4; cb++)
-        {
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-            {
-                const int col   = col0 + cb * 16 + lq + 4 * g;
-                ptr[cb * 4 + g] = reinterpret_cast<double2*>(P + (size_t)col * ldp + row0 + wave * 32 + 2 * lj);
-                v[cb * 4 + g]   = *ptr[cb * 4 + g];
-            }
-        }
 #pragma unroll
         for (int cb = 0; cb < 4; cb++)
         {

@@ -896,7 +896,7 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
     T*   rd   = V + K;                           // K: 1 / L[j][j]
     T*   t4   = rd + K;                          // 4 x K
     int* fxs  = reinterpret_cast<int*>(t4 + 4 * K); // K/2
-    int* sflg = fxs + K / 2;                     // 2
+    int* sflg = fxs + K / 2;                     // 2 flags + [2]: 16-column blocks of L that wave 0 has published
     const int k   = 2 * a.m;
     const int tid = threadIdx.x;
     auto stamp = [&](int i) {
@@ -911,6 +911,7 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
     {
         sflg[0] = 0;
         sflg[1] = 0;
+        sflg[2] = 0;
     }
     if (tid < K)
     {
@@ -1115,6 +1116,12 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
                     }
                 }
             }
+            // the 16 columns of L of this block (and their 1/diag) are complete: the inverse (wave 1) may take them
+            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS stores above have been performed
+            if (lane == 0)
+            {
+                __hip_atomic_store(&sflg[2], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             // the tiles below block row J: the block's 16 columns, four per MFMA
 #pragma unroll
             for (int I = J + 1; I < NB; I++)
@@ -1131,18 +1138,20 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
             }
         }
     }
-    else // S is in wave 0's registers: clear it for G (the inverse only writes the non-zero block rows)
+    if (tid == 0)
     {
-        for (int e = tid - 64; e < K * LD; e += 192)
+        sflg[0] = failed ? 1 : 0;
+        stamp(2);
+    }
+    // ---- wave 1: the inverse, one 16-column block behind the factorisation (it needs L[:, 16Q..16Q+15] and the
+    //      1/diag of block Q, nothing later); waves 2 and 3 wait at the barrier below
+    T chk = (T)0;
+    if (tid >= 64 && tid < 128)
+    {
+        for (int e = lane; e < K * LD; e += 64) // S is in wave 0's registers: clear it for G
         {
             S[e] = (T)0;
         }
-    }
-    __syncthreads(); // #B: L columns and 1/diag are in LDS, S is clear
-    stamp(2);
-    T chk = (T)0;
-    if (tid < 64)
-    {
         // ---- inv(L): R = I; q ascending: X[q][:] = R[q][:] / L[q][q]; R -= L[:, q] X[q][:] ----
         // G[r][c]: REF_EXACT G = inv(L) = X, TEXTBOOK G = X^T; S[r + c*LD] = G[r][c]
         const int sq = a.textbook ? LD : 1, sc = a.textbook ? 1 : LD; // X[q][c] -> S[q*sq + c*sc]
@@ -1162,6 +1171,10 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
 #pragma unroll
         for (int Q = 0; Q < NB; Q++)
         {
+            while (__hip_atomic_load(&sflg[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= Q)
+            {
+                __builtin_amdgcn_s_sleep(2);
+            }
             T X4[NB][4];
 #pragma unroll
             for (int Jc = 0; Jc < NB; Jc++)
@@ -1228,13 +1241,17 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
         const bool bad = (__ballot(!(chk == chk)) != 0ull);
         if (lane == 0)
         {
-            sflg[0] = failed ? 1 : 0;
-            sflg[1] = (!failed && bad) ? 1 : 0;
+            sflg[1] = bad ? 1 : 0;
         }
     }
     __syncthreads(); // #C
     stamp(3);
     stamp(8);
+    if (tid == 0 && sflg[0])
+    {
+        sflg[1] = 0; // (a failed factorisation is reported as such, not as a non-finite inverse)
+    }
+    __syncthreads();
     const bool zero = (sflg[0] | sflg[1]) != 0;
     if (zero) // LLT failure (slam.h:421-429 handled by the host in sync mode) or a non-finite inverse: G = 0
     {

@@ -938,6 +938,8 @@ __global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w
         s_do         = go;
         info[0]      = neff;
         info[1]      = (double)go;
+        info[2] += 1.0;        // calls and resamples since the handle was created (cslam_pf_resample_stats): lets a
+        info[3] += (double)go; // driver leave every step on the device and still report what happened
         *enable      = go;
     }
     __syncthreads();

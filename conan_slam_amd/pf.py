@@ -306,6 +306,25 @@ class ParticleShard:
                                                 C.c_int(1 if resample_status else 0), C.byref(neff), C.byref(did)))
         return float(neff.value), bool(did.value)
 
+    def observation_step(self, v, swa, Q, wb, dt, Z, idf, R, normals, select, n_effective: float, resample_status: bool):
+        """predict + sampleProposal + featureUpdate + resampleParticles for a shard that holds every particle, in one
+        C call with one staged copy; nothing returns to the host (see resample_stats)."""
+        Zc, m = self._z(Z)
+        idf = np.ascontiguousarray(idf, dtype=np.int32)
+        nrm = np.ascontiguousarray(np.asarray(normals, dtype=self.dtype).reshape(3, self.n_local))
+        sel = np.ascontiguousarray(select, dtype=self.dtype)
+        assert sel.shape[0] == self.n_local
+        check(self._L.cslam_pf_observation_step(self._h, C.c_double(float(v)), C.c_double(float(swa)), _vp(self._m22(Q)),
+                                                C.c_double(float(wb)), C.c_double(float(dt)), _vp(Zc), C.c_int(m),
+                                                _vp(idf) if m else None, _vp(self._m22(R)), _vp(nrm), _vp(sel),
+                                                C.c_double(float(n_effective)), C.c_int(1 if resample_status else 0)))
+
+    def resample_stats(self):
+        """(resample calls, resamples performed, last Neff) from the device-side counters."""
+        a, b, c = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        check(self._L.cslam_pf_resample_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), float(c.value)
+
     def pack_into(self, src_idx: np.ndarray, dptr: int):
         src_idx = np.ascontiguousarray(src_idx, dtype=np.int32)
         check(self._L.cslam_pf_pack(self._h, _vp(src_idx), C.c_int(src_idx.shape[0]), C.c_void_p(dptr)))

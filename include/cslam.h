@@ -235,6 +235,16 @@ int cslam_pf_unpack(cslam_pf_t h, const int* dst_idx, int count, const void* d_r
 int cslam_pf_resample_local(cslam_pf_t h, const void* select, double n_effective, int resample_status, double* neff,
                             int* resampled);
 int cslam_pf_gather_local(cslam_pf_t h, const int* keep, double w_new);
+/* One whole observation step of the reference's FastSLAM-2 loop (test/main.cpp:279-311) for a handle that holds every
+ * particle: PF::predict (PF.cpp:419-471), PF::sampleProposal (PF.cpp:502-544), PF::featureUpdate (PF.cpp:222-277) and
+ * PF::resampleParticles (PF.cpp:473-500), same arguments as the individual calls, with ONE staged host-to-device copy
+ * for all the small inputs and nothing returned to the host (cslam_pf_resample_stats reports what happened). */
+int cslam_pf_observation_step(cslam_pf_t h, double v, double swa, const void* Q, double wb, double dt, const void* Z, int m,
+                              const int* idf, const void* R, const void* normals, const void* select, double n_effective,
+                              int resample_status);
+/* resample calls / resamples performed since the handle was created and the last Neff (device-side counters of
+ * cslam_pf_resample_local and cslam_pf_observation_step; any pointer may be NULL).  Synchronises. */
+int cslam_pf_resample_stats(cslam_pf_t h, double* calls, double* resamples, double* last_neff);
 
 /* ---- the resample step over a particle set SHARDED across GPUs, one process (rank) per GPU:
  * PF::resampleParticles (slam.h:871-872, PF.cpp:473-500) with stratifiedResample (PF.cpp:546-574) where every rank

@@ -281,3 +281,39 @@ def test_sharded_resample_behind_the_c_abi_world_of_one(gpu_required, dtype):
         a.close()
         b.close()
     _capi.check(L.cslam_comm_destroy(comm))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_observation_step_equals_the_separate_calls(gpu_required, dtype):
+    """cslam_pf_observation_step (one staged copy, nothing returned) against predict + sampleProposal + featureUpdate +
+    resampleParticles issued one by one: the same kernels on the same inputs, so the stores must agree bit for bit."""
+    from conan_slam_amd.pf import SingleComm, resample_particles, stratified_random
+
+    npart, nf, m = 200, 9, 4
+    parts = _random_particles(npart, nf, dtype, seed=61)
+    a = _shard_from(parts, nf, dtype)
+    b = _shard_from(parts, nf, dtype)
+    rng = np.random.default_rng(62)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    n_res = 0
+    for step in range(4):
+        idf = np.sort(rng.permutation(nf)[:m] + 1).astype(np.int32)
+        Z = _obs_for(parts, idf, dtype, seed=step)
+        nrm = rng.normal(size=(3, npart)).astype(dtype)
+        sel = stratified_random(npart, rng.uniform(size=npart), dtype)
+        nmin = npart + 1 if step % 2 == 0 else int(0.5 * npart)
+        a.observation_step(83.33, 0.02 * step, Q, 73.0, 0.01, Z, idf, R, nrm, sel, nmin, True)
+        b.predict(83.33, 0.02 * step, Q, 73.0, 0.01)
+        b.sample_proposal(Z, idf, R, nrm)
+        b.feature_update(Z, idf, R)
+        _, did = resample_particles(b, SingleComm(), nmin, True, select=sel)
+        n_res += int(did)
+    calls, resamples, _ = a.resample_stats()
+    assert calls == 4 and resamples == n_res and n_res >= 2
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    for i in range(0, npart, 13):
+        for x, y in zip(a.get_particle(i), b.get_particle(i)):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), i
+    a.close()
+    b.close()
