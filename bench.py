@@ -59,8 +59,9 @@ def parse_args():
                     help="gain algebra; identical cost. REF_EXACT on this synthetic map turns every update after the "
                          "first into the reference's LLT-failure no-op (DESIGN.md), so the timed loop uses TEXTBOOK")
     ap.add_argument("--sequential", action="store_true", help="batch=false (EKF.cpp:457-479)")
-    ap.add_argument("--defer", type=int, default=0,
-                    help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = engine default)")
+    ap.add_argument("--defer", type=int, default=-1,
+                    help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = every update at once; "
+                         "default: 128 for the f32 headline -- one P-GEMM per two updates --, else 0)")
     ap.add_argument("--instances", type=int, default=8, help="mc: filter instances per GPU")
     ap.add_argument("--pgemm-wgs", type=int, default=-1,
                     help="mc: cap on each instance's persistent P-GEMM grid (-1: 512 / instances, 0: whole chip)")
@@ -241,9 +242,17 @@ def roofline_record(n, k_launch, dname, storage, launch_s, launches, landmarks, 
     traffic, tsrc = pmc_traffic(md["kernel"], landmarks, k_launch, dname)
     ach = md["bytes"] / launch_s / 1e9 if launch_s and launch_s > 0 else None
     tf = md["flops_issued"] / launch_s / 1e12 if launch_s and launch_s > 0 else None
+    # which roof bounds the launch: time to move its bytes at the HBM peak vs time to issue its flops at the MFMA peak
+    t_hbm = md["bytes"] / (HBM_PEAK_GBS * 1e9)
+    t_mfma = md["flops_issued"] / (MFMA_PEAK_TF[dname] * 1e12)
+    mfma_bound = t_mfma > t_hbm
     rec = {
-        "kernel": md["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": (ach / HBM_PEAK_GBS) if ach else None,
+        "kernel": md["kernel"], "bound": "mfma" if mfma_bound else "hbm",
+        "achieved": tf if mfma_bound else ach, "peak": MFMA_PEAK_TF[dname] if mfma_bound else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if mfma_bound else "GB/s",
+        "frac": ((tf / MFMA_PEAK_TF[dname]) if tf else None) if mfma_bound else ((ach / HBM_PEAK_GBS) if ach else None),
+        "hbm_gbs": ach, "hbm_frac": (ach / HBM_PEAK_GBS) if ach else None,
+        "roof_times_us": {"hbm": t_hbm * 1e6, "mfma": t_mfma * 1e6},
         "traffic": traffic,
         "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if traffic else None,
         "algorithmic_bytes_per_launch": md["bytes"],
@@ -289,9 +298,14 @@ def ekf_main(args):
     quirks = Q_TEXTBOOK if args.quirks == "textbook" else Q_REF_EXACT
     eng = EKF(N, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
     eng.set_state(w.X0, w.P0)
+    if args.defer < 0:
+        # the engine's deferred-downdate mode (P = Ps - Wp Wp^T; every update is applied to the state, and to the
+        # covariance through the pending-panel correction): one k = 128 P-GEMM per two updates moves P half as often
+        args.defer = 128 if (args.dtype == "f32" and not args.sequential and 2 * args.obs == 64) else 0
     if args.defer > 0:
         eng.set_deferred(args.defer)
-    inp = DeviceInputs(torch, w, total + n_bracket + n_call + n_drop)
+    n_imm = args.steps if (extras and args.defer > 0) else 0
+    inp = DeviceInputs(torch, w, total + n_bracket + n_call + n_drop + n_imm)
     batch = not args.sequential
 
     def step(t):
@@ -388,6 +402,30 @@ def ekf_main(args):
         st = eng.stage_times()
         eng.set_profiling(0)
         out["stage_us"] = {name: (ms / max(cnt, 1)) * 1e3 for name, (ms, cnt) in st.items()}
+    if n_imm:
+        # the same K steps with every update's P-GEMM applied at once (cslam_ekf_set_deferred(0)), its own roofline
+        eng.flush()
+        eng.set_deferred(0)
+        for t in range(t_next, t_next + min(10, n_imm)):
+            step(t)
+        eng.set_profiling(3 if n_imm >= 200 else 4)
+        barrier()
+        c0 = time.perf_counter()
+        for t in range(t_next, t_next + n_imm):
+            step(t)
+        eng.flush()
+        eng.synchronize()
+        el = time.perf_counter() - c0
+        st = eng.stage_times()
+        eng.set_profiling(0)
+        t_next += n_imm
+        i_ms, i_cnt = st["downdate"]
+        out["immediate_mode"] = {
+            "value": n_imm / el, "unit": "update steps/s", "ms_per_step": el / n_imm * 1e3,
+            "note": "cslam_ekf_set_deferred(0): every update launches its own k = 64 P-GEMM (one sweep of P per update)",
+            "roofline": roofline_record(n, k, args.dtype, storage, (i_ms / i_cnt) * 1e-3 if i_cnt else None, i_cnt, N),
+        }
+        eng.set_deferred(args.defer)
     if extras:
         # per-call times with X returned to the host each call (asynchronous engine, inputs in HBM)
         ts = []
@@ -402,6 +440,8 @@ def ekf_main(args):
                                steps_per_sec_at_median=1e3 / quantiles_ms(ts[8:])["median_ms"])
         # what INTEGRATION.md's adapter does per call: sync mode (host-side eigen fallback armed), host Z / idf,
         # X read back after predict and after update (slam.h:841-847, 938-943 pass X by reference)
+        eng.flush()
+        eng.set_deferred(0)  # (a caller that only swaps the class in never asks for deferral)
         eng.set_sync_mode(True)
         ts = []
         for t in range(t_next, t_next + n_drop):
@@ -414,6 +454,7 @@ def ekf_main(args):
             eng.get_x()
             ts.append(time.perf_counter() - c0)
         eng.set_sync_mode(False)
+        eng.set_deferred(args.defer)
         t_next += n_drop
         q = quantiles_ms(ts[8:])
         out["dropin"] = dict(q, value=1e3 / q["median_ms"], unit="update steps/s",

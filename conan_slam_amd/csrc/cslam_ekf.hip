@@ -1134,10 +1134,14 @@ struct Ekf : EkfBase
             }
             else if (k <= 4)
             {
+                a.dM    = dM;
+                m_valid = true;
                 hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
             }
             else if (k <= 16)
             {
+                a.dM    = dM;
+                m_valid = true;
                 hipLaunchKernelGGL((ekf_factor_small_kernel<T, 16>), dim3(1), dim3(256), 0, stream, a, dU);
             }
             else if (k <= 32)
@@ -1225,8 +1229,8 @@ struct Ekf : EkfBase
         // a few pending columns (heading observations) are corrected for inside the gather kernel: the fast path stays
         const bool small_corr = kp > 0 && kp <= kGatherCorr && !pipeline;
         // a pending predict() rides along when this batch takes the (non-pipelined) fast path
-        fuse_now = pp.valid && sizeof(T) == 4 && !pipeline && !keep_pending && (kp == 0 || small_corr) && k > 16 &&
-                   k <= 64 && tune_factor == 0 && tune_gain == 0;
+        fuse_now = pp.valid && sizeof(T) == 4 && !pipeline && !keep_pending && k > 16 && k <= 64 && tune_factor == 0 &&
+                   tune_gain == 0;
         if ((rc = fuse_now ? launch_pose_queue() : resolve_predict())) // (queued control steps come first either way)
         {
             return rc;
@@ -1268,8 +1272,9 @@ struct Ekf : EkfBase
         PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
         hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, dPv, ldp, n, dZ, dIdf, m, dPHT, ldp,
                            lower, sub_valid ? dSub : nullptr, fuse_now ? pp : pnone, fuse_now ? dPred : (T*)nullptr,
-                           small_corr ? (const T*)wbase(wcur) : (const T*)nullptr, ldp, small_corr ? kp : 0,
-                           (small_corr && hd_cols[wcur] > 0) ? dSign + (size_t)wcur * wcap : (const int*)nullptr);
+                           (kp > 0 && !pipeline) ? (const T*)wbase(wcur) : (const T*)nullptr, ldp, pipeline ? 0 : kp,
+                           (kp > 0 && !pipeline && hd_cols[wcur] > 0) ? dSign + (size_t)wcur * wcap : (const int*)nullptr, dFlags,
+                           (kp > 0 && !small_corr && !pipeline) ? dY : (T*)nullptr);
         CSLAM_HIP_TRY(hipGetLastError());
         // the panels this update's P*H^T must be corrected with, and where its own W1 goes
         const T*  Wc        = wbase(wcur);
@@ -1289,9 +1294,13 @@ struct Ekf : EkfBase
         }
         if (kc > 0 && !small_corr) // PHT -= Wp * (H*Wp)^T : the pending panels' share of P*H^T (their pose rows are zero)
         {
-            hipLaunchKernelGGL(ekf_pending_y_kernel<T>, dim3(m, (kc + 255) / 256), dim3(256), 0, stream, dX, n, dZ, dIdf, m,
-                               Wc, ldp, kc, dY, hd_cols[rc_region] > 0 ? dSign + (size_t)rc_region * wcap : (const int*)nullptr);
-            CSLAM_HIP_TRY(hipGetLastError());
+            if (pipeline) // (single stream: the gather kernel has published Y = H*Wp already)
+            {
+                hipLaunchKernelGGL(ekf_pending_y_kernel<T>, dim3(m, (kc + 255) / 256), dim3(256), 0, stream, dX, n, dZ, dIdf,
+                                   m, Wc, ldp, kc, dY,
+                                   hd_cols[rc_region] > 0 ? dSign + (size_t)rc_region * wcap : (const int*)nullptr);
+                CSLAM_HIP_TRY(hipGetLastError());
+            }
             if (!launch_corr_fast(k, Wc, kc))
             {
                 hipLaunchKernelGGL(ekf_pending_corr_kernel<T>, ggrid, dim3(256), 0, stream, n, m, Wc, ldp, kc, dY, dPHT,
@@ -1541,6 +1550,10 @@ struct Ekf : EkfBase
         if (hFlags[0] & kFlagZeroed)
         {
             f |= CSLAM_FACTOR_ZEROED;
+        }
+        if (hFlags[0] & kFlagBadIdf)
+        {
+            f |= CSLAM_FACTOR_BAD_IDF;
         }
         if ((hFlags[0] & kFlagLltFailed) && !(sticky_host & CSLAM_FACTOR_FALLBACK))
         {

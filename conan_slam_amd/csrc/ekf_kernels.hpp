@@ -26,6 +26,16 @@ namespace cslam
 
 constexpr int kFlagLltFailed = 1; // device-side factor flags
 constexpr int kFlagZeroed    = 2;
+constexpr int kFlagBadIdf    = 8; // a feature index outside 1..(n-3)/2 reached the device (cslam_ekf_update_device)
+
+// Feature indices that arrive through device memory cannot be checked by the host: every kernel clamps them into
+// 1..(n-3)/2 before it forms an address (no out-of-bounds access whatever the caller sends) and the gather kernel
+// raises kFlagBadIdf.
+__device__ inline int clamp_idf(int idf, int n)
+{
+    const int nf = (n - 3) >> 1;
+    return idf < 1 ? 1 : (idf > nf ? (nf > 0 ? nf : 1) : idf);
+}
 
 typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -74,7 +84,7 @@ template <typename T>
 __device__ inline void observe_model_pose(const T* __restrict__ X, int n, int idf, T zr, T zb, T px, T py, T pphi, T* coef,
                                           T* v, int* fx)
 {
-    int f = 3 + 2 * idf - 2;
+    int f = 3 + 2 * clamp_idf(idf, n) - 2;
     *fx   = f;
     if (n > 3)
     {
@@ -240,7 +250,7 @@ __device__ inline void predict_pvv(const PredictArgs<T>& pp, T phi_old, const T*
 // (EKF.cpp:394-395), which in column-major P are contiguous columns -> fully coalesced reads.
 // grid = (ceil(n/256), ceil(m/kGatherObs)), block = 256.
 // ------------------------------------------------------------------------------------------------
-constexpr int kGatherCorr = 8; // pending columns the gather kernel corrects for by itself
+constexpr int kGatherCorr = 16; // pending columns the gather kernel corrects for by itself
 constexpr int kGatherObs = 1; // measured at N = 5000, m = 32: 11.1 us (8 per block), 10.2 (4), 9.5 (2), 8.7 (1): the kernel is a latency chain, more blocks win
 
 template <typename T>
@@ -253,8 +263,21 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
                                                                                              (T)0, (T)0, (T)0, (T)0, 0},
                                                           T* __restrict__ pred_out = nullptr,
                                                           const T* __restrict__ Wc = nullptr, int ldwc = 0, int kc = 0,
-                                                          const int* __restrict__ sgn = nullptr)
+                                                          const int* __restrict__ sgn = nullptr,
+                                                          int* __restrict__ flags = nullptr,
+                                                          T* __restrict__ Yout = nullptr)
 {
+    // Yout (kc > kGatherCorr): the pending panels are too many to correct for here: this kernel only publishes
+    // Y = H*Wc (k x kc, Y[q*k + row]) -- with the coefficients of the (possibly predicted) pose it has anyway -- and the
+    // MFMA panel kernel applies PHT -= Wc*Y^T behind it.
+    if (flags != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < m)
+    {
+        const int id = idf[threadIdx.x];
+        if (id < 1 || id > ((n - 3) >> 1))
+        {
+            atomicOr(&flags[0], kFlagBadIdf);
+        }
+    }
     // Wc / kc (kc <= kGatherCorr): a FEW pending columns (heading observations: rank-1 columns, ekf_pose_step_kernel)
     // are corrected for right here -- PHT = Ps*H^T - Wc*(H*Wc)^T with H*Wc built per workgroup from the two landmark
     // rows of Wc (its pose rows are zero) -- so that the update keeps its fast path (compact block, fused predict)
@@ -287,7 +310,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
 #pragma unroll
     for (int oo = 0; oo < kGatherObs; oo++)
     {
-        fxe[oo] = 3 + 2 * idf[o0 + min(oo, no - 1)] - 2; // as observe_model_pose
+        fxe[oo] = 3 + 2 * clamp_idf(idf[o0 + min(oo, no - 1)], n) - 2; // as observe_model_pose
         ea[oo]  = p_get<T>(P, Pv, ldp, il, fxe[oo], lower);
         eb[oo]  = p_get<T>(P, Pv, ldp, il, fxe[oo] + 1, lower);
     }
@@ -296,7 +319,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
 #pragma unroll
     for (int q = 0; q < kGatherCorr; q++)
     {
-        wc[q] = (q < kc) ? Wc[(size_t)q * ldwc + il] : (T)0;
+        wc[q] = (q < kc && Yout == nullptr) ? Wc[(size_t)q * ldwc + il] : (T)0;
     }
     __shared__ T s_y[kGatherObs][2][kGatherCorr];
     if (pp.valid && i < 3)
@@ -332,7 +355,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         __syncthreads(); // s_cand = 0 above
         if ((int)threadIdx.x < m && threadIdx.x < 32)
         {
-            const int id        = idf[threadIdx.x];
+            const int id        = clamp_idf(idf[threadIdx.x], n);
             s_idf[threadIdx.x]  = id;
             const int fxo       = 3 + 2 * id - 2; // first state row of that landmark
             const int i0        = blockIdx.x * 256;
@@ -343,7 +366,27 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         }
     }
     __syncthreads();
-    if (kc > 0) // (workgroup-uniform)
+    if (Yout != nullptr && blockIdx.x == 0) // (workgroup-uniform) one workgroup per observation publishes its two rows of Y
+    {
+        for (int e = threadIdx.x; e < no * kc; e += 256)
+        {
+            const int oo = e / kc, q = e - oo * kc;
+            const T*  c  = &s_coef[oo * 10];
+            const T   wa = Wc[(size_t)q * ldwc + s_fx[oo]], wb = Wc[(size_t)q * ldwc + s_fx[oo] + 1];
+            T         y0 = c[3] * wa;
+            y0 += c[4] * wb;
+            T y1 = c[8] * wa;
+            y1 += c[9] * wb;
+            if (sgn != nullptr && sgn[q] != 0)
+            {
+                y0 = -y0;
+                y1 = -y1;
+            }
+            Yout[(size_t)q * (2 * m) + 2 * (o0 + oo)]     = y0;
+            Yout[(size_t)q * (2 * m) + 2 * (o0 + oo) + 1] = y1;
+        }
+    }
+    if (kc > 0 && Yout == nullptr) // (workgroup-uniform)
     {
         // Y = H*Wc for this workgroup's observations: only the landmark columns of H meet non-zero rows of Wc
         if ((int)threadIdx.x < no * kGatherCorr)
@@ -461,7 +504,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         s1 += p2 * c[7];
         s1 += a * c[8];
         s1 += b * c[9];
-        if (kc > 0)
+        if (kc > 0 && Yout == nullptr)
         {
             T c0 = (T)0, c1 = (T)0;
 #pragma unroll

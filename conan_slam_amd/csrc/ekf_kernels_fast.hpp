@@ -311,6 +311,46 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
         {
             du[o] = s2;
         }
+        // M[:, c] = G (G^T PHT[c, :]^T), c = 0..2: lets the gain kernel apply the pose-stripe downdate itself
+        // (see ekf_factor_mfma_f32; the sequential update runs this kernel once per observation)
+        if (a.dM != nullptr)
+        {
+            for (int c = 0; c < 3; c++)
+            {
+                __syncthreads();
+                T s3 = (T)0;
+                if (o < K)
+                {
+#pragma unroll 4
+                    for (int r = part; r < K; r += 4)
+                    {
+                        s3 += S[r + o * LD] * ((r < k) ? a.PHT[(size_t)r * a.ldw + c] : (T)0);
+                    }
+                }
+                s3 += __shfl_xor(s3, 1);
+                s3 += __shfl_xor(s3, 2);
+                if (part == 0 && o < K)
+                {
+                    tvec[o] = (o < k) ? s3 : (T)0;
+                }
+                __syncthreads();
+                T s4 = (T)0;
+                if (o < K)
+                {
+#pragma unroll 4
+                    for (int q = part; q < K; q += 4)
+                    {
+                        s4 += S[o + q * LD] * tvec[q];
+                    }
+                }
+                s4 += __shfl_xor(s4, 1);
+                s4 += __shfl_xor(s4, 2);
+                if (part == 0 && o < k)
+                {
+                    a.dM[c * k + o] = s4;
+                }
+            }
+        }
     }
     stamp(4);
     if (tid == 0)

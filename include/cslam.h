@@ -44,6 +44,8 @@ extern "C" {
 #define CSLAM_FACTOR_FALLBACK 1 /* LLT of S failed; eigen "square root" taken (slam.h:425-429)        */
 #define CSLAM_FACTOR_ZEROED 2   /* factor or its inverse non-finite -> update was a no-op (slam.h:252-255, 431-434) */
 #define CSLAM_FACTOR_SKIPPED 4  /* async mode: LLT failed and the update was skipped (see set_sync_mode) */
+#define CSLAM_FACTOR_BAD_IDF 8  /* cslam_ekf_update_device: a device-resident feature index was outside 1..N; the kernels
+                                   clamped it (no out-of-bounds access), the update used the clamped index           */
 
 /* ---- precision ---- */
 #define CSLAM_F32 0 /* the reference's precision (Eigen::MatrixXf everywhere)                          */
@@ -103,7 +105,9 @@ int cslam_ekf_predict(cslam_ekf_t h, double v, double swa, const void* Q, double
  * memory, consumed before return.  m = 0 is a no-op, as in the reference. */
 int cslam_ekf_update(cslam_ekf_t h, const void* Z, int m, const void* R, const int* idf, int batch);
 
-/* Same, with Z and idf already resident in device memory (HBM); R stays a host pointer (4 scalars). */
+/* Same, with Z and idf already resident in device memory (HBM); R stays a host pointer (4 scalars).  The host cannot
+ * check device-resident indices: every kernel clamps them into 1..N before it forms an address and
+ * CSLAM_FACTOR_BAD_IDF is raised (cslam_ekf_factor_status) when one was out of range. */
 int cslam_ekf_update_device(cslam_ekf_t h, const void* dZ, int m, const void* R, const int* d_idf, int batch);
 
 /* Replaces Slam::augment(X, P, Z, R)  -- slam.h:190-191, EKF.cpp:9-26 / addOneNewFeature EKF.cpp:28-91.

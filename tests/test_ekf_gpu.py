@@ -689,3 +689,27 @@ def test_pipelined_and_single_stream_engines_agree(gpu_required, monkeypatch):
     assert_close("P", Pa, Pb, 2e-4)
     a.close()
     b.close()
+
+
+def test_device_resident_bad_feature_index_is_flagged_not_faulted(gpu_required):
+    """cslam_ekf_update_device cannot check indices that live in HBM: the kernels clamp them (no out-of-bounds access)
+    and CSLAM_FACTOR_BAD_IDF is raised."""
+    import torch
+
+    from conan_slam_amd import _capi
+
+    N, m = 40, 6
+    X, P = make_scenario(N, np.float32, seed=6, corr=0.2)
+    eng = _engine(N, np.float32, REF_EXACT, X, P)
+    idf = np.array([3, 9, 10 ** 6, 12, -5, 20], dtype=np.int32)
+    Z = make_obs(X, np.clip(idf, 1, N), np.float32)
+    R = np.diag([0.08, 0.0024]).astype(np.float32)
+    dZ = torch.from_numpy(np.ascontiguousarray(Z.reshape(-1, order="F"))).cuda()
+    dI = torch.from_numpy(idf).cuda()
+    torch.cuda.synchronize()
+    eng.update_device(dZ.data_ptr(), m, R, dI.data_ptr(), batch=True)
+    st = eng.factor_status()
+    assert st & _capi.FACTOR_BAD_IDF
+    Xg, Pg = eng.get_state()
+    assert np.all(np.isfinite(Xg)) and np.all(np.isfinite(Pg))
+    eng.close()
