@@ -218,9 +218,10 @@ def pgemm_model(n, k_launch, dname, storage):
     full_bytes = 2.0 * n * n * s + 1.0 * n * k_launch * s  # full-storage P read + written, W1 read once
     if storage == "lower":
         nt = sym_tiles(n)
-        chunks = 2 if k8 <= 64 else (4 if k8 <= 128 else (k8 + 63) // 64 * 2)
-        name = "ekf_downdate_psym4_f32<0,%d>" % (2 if k8 <= 64 else 4) if k8 <= 128 else "ekf_downdate_psym_f32<64,true,false>"
-        return {"kernel": name, "bytes": nt * 65536.0 * 2 + 1.0 * n * k8 * s, "flops_issued": nt * 128.0 * 128.0 * chunks * 32 * 2,
+        depth = 64 if k8 <= 64 else (96 if k8 <= 96 else (128 if k8 <= 128 else (k8 + 63) // 64 * 64))  # chunks x chunk depth
+        name = ("ekf_downdate_psym4_f32<0,2,32>" if k8 <= 64 else ("ekf_downdate_psym4_f32<0,4,24>" if k8 <= 96 else
+                "ekf_downdate_psym4_f32<0,4,32>")) if k8 <= 128 else "ekf_downdate_psym_f32<64,true,false>"
+        return {"kernel": name, "bytes": nt * 65536.0 * 2 + 1.0 * n * k8 * s, "flops_issued": nt * 128.0 * 128.0 * depth * 2,
                 "full_storage_bytes": full_bytes, "n_sym_tiles": nt}
     tiles = ((n + 127) // 128) ** 2
     return {"kernel": "ekf_downdate_" + dname, "bytes": full_bytes, "flops_issued": tiles * 128.0 * 128.0 * k8 * 2,
