@@ -466,6 +466,11 @@ def ekf_main(args):
     eng.close()
     if extras and args.dtype == "f32":
         out["reference_loop"] = reference_loop(args, torch, w, N, quirks)
+        if quirks != Q_REF_EXACT:
+            # the reference-faithful gain (lower-Cholesky factor, n-4 stripe) at size: the heading observation on
+            # every control step is what keeps the reference's own filter healthy; factor_flags tells
+            # whether it stayed so on this map
+            out["reference_loop_ref_exact"] = reference_loop(args, torch, w, N, Q_REF_EXACT)
     if world == 1 and not args.no_cpu_baseline:
         w.P0 = None
         out["cpu_baseline"] = cpu_baseline(N, args.obs, dtype, args.dtype, args.quirks, args.cpu_baseline_seconds)

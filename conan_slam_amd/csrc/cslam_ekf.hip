@@ -139,6 +139,7 @@ struct Ekf : EkfBase
     int*       dTicket     = nullptr; // two tile-ticket counters used alternately by successive P-GEMM launches
     unsigned   launch_parity = 0;
     int        psym_nt = -1; // CSLAM_PSYM_NT: non-temporal P accesses in the P-GEMM (-1: by footprint)
+    int        psym_prefetch = -1; // CSLAM_PSYM_PREFETCH: software-pipelined LDS operands in the P-GEMM (-1: by chunk count)
     unsigned long long* dHwIds = nullptr; // CSLAM_PSYM_HWID=1 (diagnostics)
     int        hwid_prints = 0;
     int        stagger_mode = 0, stagger_cycles = 0; // CSLAM_PSYM_STAGGER=mode,cycles
@@ -321,6 +322,10 @@ struct Ekf : EkfBase
         if (const char* sv = getenv("CSLAM_PSYM_NT"))
         {
             psym_nt = atoi(sv);
+        }
+        if (const char* sv = getenv("CSLAM_PSYM_PREFETCH"))
+        {
+            psym_prefetch = atoi(sv);
         }
         if (getenv("CSLAM_PSYM_HWID"))
         {
@@ -1754,10 +1759,21 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
             launch_parity++;
             const bool nt     = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
             const int  ntmode = psym_nt >= 0 ? psym_nt : (nt ? 1 : 0);
-#define CSLAM_LAUNCH_PSYM4(MODE, NCH)                                                                               \
-    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE, NCH>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k, dTiles,   \
-                       n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds)
-            if (k8 <= 64)
+#define CSLAM_LAUNCH_PSYM4X(MODE, NCH, KC, PF)                                                                        \
+    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE, NCH, KC, PF>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k,     \
+                       dTiles, n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds)
+#define CSLAM_LAUNCH_PSYM4(MODE, NCH) CSLAM_LAUNCH_PSYM4X(MODE, NCH, 32, false)
+            // software-pipelined LDS operands (see the kernel): an A/B switch, CSLAM_PSYM_PREFETCH=1
+            // (measured, N = 5000: k = 128 119.3 vs 119.4 us, k = 64 80.6 vs 85.5 us without / with: two waves per SIMD
+            // already hide the LDS latency, so it stays off)
+            const bool pf4 = psym_prefetch > 0;
+            const bool pf2 = psym_prefetch > 0;
+            if (k8 <= 64 && pf2 && ntmode <= 1)
+            {
+                if (ntmode == 1) { CSLAM_LAUNCH_PSYM4X(1, 2, 32, true); }
+                else { CSLAM_LAUNCH_PSYM4X(0, 2, 32, true); }
+            }
+            else if (k8 <= 64)
             {
                 if (ntmode == 1) { CSLAM_LAUNCH_PSYM4(1, 2); }
                 else if (ntmode == 2) { CSLAM_LAUNCH_PSYM4(2, 2); }
@@ -1771,20 +1787,25 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
             {
                 if (ntmode == 1)
                 {
-                    hipLaunchKernelGGL((ekf_downdate_psym4_f32<1, 4, 24>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k, dTiles,
-                                       n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds);
+                    if (pf4) { CSLAM_LAUNCH_PSYM4X(1, 4, 24, true); } else { CSLAM_LAUNCH_PSYM4X(1, 4, 24, false); }
                 }
                 else
                 {
-                    hipLaunchKernelGGL((ekf_downdate_psym4_f32<0, 4, 24>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k, dTiles,
-                                       n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds);
+                    if (pf4) { CSLAM_LAUNCH_PSYM4X(0, 4, 24, true); } else { CSLAM_LAUNCH_PSYM4X(0, 4, 24, false); }
                 }
             }
             else
             {
-                if (ntmode == 1) { CSLAM_LAUNCH_PSYM4(1, 4); }
-                else { CSLAM_LAUNCH_PSYM4(0, 4); }
+                if (ntmode == 1)
+                {
+                    if (pf4) { CSLAM_LAUNCH_PSYM4X(1, 4, 32, true); } else { CSLAM_LAUNCH_PSYM4X(1, 4, 32, false); }
+                }
+                else
+                {
+                    if (pf4) { CSLAM_LAUNCH_PSYM4X(0, 4, 32, true); } else { CSLAM_LAUNCH_PSYM4X(0, 4, 32, false); }
+                }
             }
+#undef CSLAM_LAUNCH_PSYM4X
 #undef CSLAM_LAUNCH_PSYM4
         }
         else if (k8 <= 64 && tune_downdate != 2)

@@ -3094,7 +3094,10 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
 // c & 1; the stores go behind chunk 0, the loads behind chunk 0/1 (NCH = 2) or chunks 1 and 2 (NCH = 4).
 // KC: columns per chunk (32; 24 with NCH = 4 covers 64 < k <= 96 -- an update's 64 columns plus a few rank-1 heading
 // columns -- at 1.5x instead of 2x the matrix-core work of k = 64, which keeps that launch bandwidth-bound).
-template <int NTMODE, int NCH, int KC = 32>
+// PF: the LDS operands of k-pair g+1 are requested BEFORE the four MFMAs of k-pair g are issued (software pipelining:
+// the scheduling barriers between k-pairs otherwise put every group's LDS latency in front of its MFMAs).  It matters
+// where the launch is matrix-bound (k = 128: 4 chunks).
+template <int NTMODE, int NCH, int KC = 32, bool PF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
                        const int2* __restrict__ tile_list, int ntiles, int* __restrict__ ticket,
@@ -3252,10 +3255,40 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
                 dma_chunk(have_next ? nxt : cur, C0{}); // (re-reads this tile's panel after the last tile: harmless)
             }
             __builtin_amdgcn_sched_barrier(0);
+            float4 b_cur = make_float4(0.f, 0.f, 0.f, 0.f);
+            float  a_cur = 0.f;
+            if constexpr (PF)
+            {
+                const float* sB = (c & 1) == 0 ? s_b0 : s_b1;
+                const float* sA = (c & 1) == 0 ? s_a0 : s_a1;
+                b_cur           = *reinterpret_cast<const float4*>(&sB[lh * 128 + 4 * lj]);
+                a_cur           = sA[lh * 128 + wave * 32 + lj];
+            }
 #pragma unroll
             for (int g = 0; g < KC / 2; g++)
             {
-                mfma_group(std::integral_constant<int, (c & 1)>{}, g);
+                if constexpr (PF)
+                {
+                    const float* sB = (c & 1) == 0 ? s_b0 : s_b1;
+                    const float* sA = (c & 1) == 0 ? s_a0 : s_a1;
+                    float4       b_nxt = b_cur;
+                    float        a_nxt = a_cur;
+                    if (g + 1 < KC / 2)
+                    {
+                        b_nxt = *reinterpret_cast<const float4*>(&sB[(2 * (g + 1) + lh) * 128 + 4 * lj]);
+                        a_nxt = sA[(2 * (g + 1) + lh) * 128 + wave * 32 + lj];
+                    }
+                    acc0  = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.x, acc0, 0, 0, 0);
+                    acc1  = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.y, acc1, 0, 0, 0);
+                    acc2  = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.z, acc2, 0, 0, 0);
+                    acc3  = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.w, acc3, 0, 0, 0);
+                    b_cur = b_nxt;
+                    a_cur = a_nxt;
+                }
+                else
+                {
+                    mfma_group(std::integral_constant<int, (c & 1)>{}, g);
+                }
                 if (c == 0 && g < 8 && !first)
                 {
                     store1(prev_base, 2 * g, pv[2 * g]);

@@ -52,22 +52,16 @@ def stratified_random(n: int, uniforms: np.ndarray, dtype=np.float32) -> np.ndar
 
 
 def stratified_keep(w_norm: np.ndarray, select: np.ndarray) -> np.ndarray:
-    """PF.cpp:559-574 (intended form): 0-based index of the particle each slot keeps."""
+    """PF.cpp:559-574 (intended form): 0-based index of the particle each slot keeps = the first i whose running weight
+    sum exceeds the slot's stratum position (none: 0, as the reference's zero-initialised Keep).  The running sum is
+    sequential in the particle dtype (np.cumsum accumulates in index order in the requested dtype: the reference's
+    sequence of roundings); the search is what pf_resample_plan_kernel / pf_keep_kernel do on the device."""
     dtype = w_norm.dtype
     n = w_norm.shape[0]
-    cum = np.empty(n, dtype=dtype)
-    s = dtype.type(w_norm[0])
-    cum[0] = s
-    for i in range(1, n):
-        s = dtype.type(s + w_norm[i])
-        cum[i] = s
-    keep = np.zeros(n, dtype=np.int32)
-    ctr = 1
-    for i in range(n):
-        while ctr <= n and select[ctr - 1] < cum[i]:
-            keep[ctr - 1] = i
-            ctr += 1
-    return keep
+    cum = np.cumsum(w_norm, dtype=dtype)
+    keep = np.searchsorted(cum, np.asarray(select, dtype=dtype), side="right")
+    keep[keep >= n] = 0
+    return keep.astype(np.int32)
 
 
 def plan_exchange(keep: np.ndarray, rank: int, world: int, n_local: int):

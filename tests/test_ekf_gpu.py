@@ -530,6 +530,23 @@ def test_data_association_at_full_size_and_under_pending_downdates(gpu_required)
     # (a 5000-landmark random map has near-coincident landmarks: a few observations are closer, in the normalised
     # distance, to a neighbour than to the feature they were generated from)
     assert hit.sum() >= 0.8 * len(idf) and (ia[hit] == np.asarray(idf)[hit]).mean() >= 0.8
+    # ... and against the oracle at this size: the full sequential search is O(m N n^2) on the CPU, so the oracle's
+    # per-pair quantities (EKF.cpp:131-144) are compared instead: the feature the engine chose must lie inside gate 1 and
+    # be at least as close (normalised distance) as the feature the observation was generated from
+    from pyoracle import Oracle
+
+    o = Oracle(np.float32, TEXTBOOK)
+    Xa, Pa = a.get_state()
+    n = Xa.shape[0]
+    Pa = np.asfortranarray(Pa)
+    checked = 0
+    for i in np.nonzero(hit)[0][:12]:
+        nis_e, nd_e = o.compute_association(Xa, Pa, n, Z[:, i].copy(), w.RE, int(ia[i]))
+        nis_t, nd_t = o.compute_association(Xa, Pa, n, Z[:, i].copy(), w.RE, int(idf[i]))
+        assert nis_e < 9.0 * (1 + 1e-3), (i, nis_e)
+        assert nd_e <= nd_t + 1e-3 * max(1.0, abs(nd_t)), (i, ia[i], idf[i], nd_e, nd_t)
+        checked += 1
+    assert checked >= 8
     a.close()
     b.close()
 

@@ -122,21 +122,39 @@ def test_feature_update(gpu_required, dtype, quirks, m):
 @pytest.mark.parametrize("m", [1, 4])
 def test_sample_proposal(gpu_required, dtype, m):
     o = Oracle(dtype)
+    o64 = Oracle(np.float64)
     nf = 6
     npart = 130
     parts = _random_particles(npart, nf, dtype, seed=5)
+    hi = [[np.float64(p[0])] + [np.array(a, dtype=np.float64, order="F") for a in p[1:]] for p in parts]
     sh = _shard_from(parts, nf, dtype)
     idf = np.array([3, 1, 6, 4][:m], dtype=np.int32)
     Z = _obs_for(parts, idf, dtype)
     R = np.diag([0.08, 0.0024]).astype(dtype)
     normals = np.random.default_rng(9).normal(size=(3, npart)).astype(dtype)
     sh.sample_proposal(Z, idf, R, normals)
-    for i, p in enumerate(parts):
+    for i, (p, h) in enumerate(zip(parts, hi)):
         w = np.array([p[0]], dtype=dtype)
         o.pf_sample_proposal(w, p[1], p[2], p[3], p[4], Z, idf, R, normals[:, i].copy())
         p[0] = w[0]
-    # the weight is a product of Gaussian densities: compare relatively
-    _compare(sh, parts, dtype, f"sample_proposal m={m}", wtol=5e-3 if dtype == np.float32 else 1e-9)
+        wh = np.array([h[0]], dtype=np.float64)
+        o64.pf_sample_proposal(wh, h[1], h[2], h[3], h[4], Z.astype(np.float64), idf, R.astype(np.float64),
+                               normals[:, i].astype(np.float64))
+        h[0] = wh[0]
+    # pose / map against the same-precision oracle; the weight is a product of Gaussian densities (exp of a
+    # quadratic form in an inverse): the fairness rule of SURVEY 8d against the f64 oracle replaces a fixed tolerance
+    _compare(sh, parts, dtype, f"sample_proposal m={m}", wtol=np.inf)
+    wg = sh.get_weights().astype(np.float64)
+    wc = np.array([p[0] for p in parts], dtype=np.float64)
+    wh = np.array([h[0] for h in hi], dtype=np.float64)
+    ok = wh > 1e-30  # (densities far out in the tails underflow to zero in f32, on the device as in the oracle)
+    assert ok.sum() >= 1 and np.all(np.abs(wg[~ok]) <= 1e-30) and np.all(np.isfinite(wg))
+    e_gpu, e_cpu = np.abs(wg[ok] - wh[ok]) / wh[ok], np.abs(wc[ok] - wh[ok]) / wh[ok]
+    if dtype == np.float64:
+        assert np.abs(wg - wc).max() <= 1e-9 * np.abs(wc).max()
+    else:
+        assert e_gpu.max() <= 4.0 * e_cpu.max() + 1e-6, (e_gpu.max(), e_cpu.max())
+        assert np.median(e_gpu) <= 4.0 * np.median(e_cpu) + 1e-7, (np.median(e_gpu), np.median(e_cpu))
     sh.close()
 
 

@@ -1,5 +1,10 @@
 R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r2_trace3 -o run -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extras > $R/gpurun_out/r2_trace3.log 2>&1
-python3 $R/tools/trace_timeline.py $R/gpurun_out/r2_trace3/run_kernel_trace.csv 0.5 24 > $R/gpurun_out/r2_timeline3.txt
-cat $R/gpurun_out/r2_timeline3.txt
+cd $R
+python -m pytest tests -q -m gpu -x > gpurun_out/r2_t16.log 2>&1; echo "tests rc=$?"
+tail -3 gpurun_out/r2_t16.log
+python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline > gpurun_out/r2_b8.json 2>gpurun_out/r2_b8.err || tail -5 gpurun_out/r2_b8.err
+python3 -c "
+import json;d=json.load(open('gpurun_out/r2_b8.json'))
+print('headline', round(d['value']), d['ms_per_step'])
+for k in ('reference_loop','reference_loop_ref_exact'): print(k, {kk:vv for kk,vv in d[k].items() if kk!='note'})
+"
