@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per_call / dropin / reference_loop sub-records")
     ap.add_argument("--stage-profile", action="store_true", help="extra untimed pass with events around every stage")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a box with ONE GPU: every rank uses device 0 and the ranks rendezvous "
+                         "over gloo (RCCL refuses one device twice); exercises the launcher / rank logic, not xGMI")
     return ap.parse_args()
 
 
@@ -93,26 +96,36 @@ def launch_ranks_if_needed(args):
     raise SystemExit(subprocess.run(cmd).returncode)
 
 
-def dist_setup():
+_REHEARSE = False
+
+
+def dist_setup(args=None):
+    global _REHEARSE
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
 
+    _REHEARSE = bool(args is not None and getattr(args, "rehearse_one_gpu", False))
+    if _REHEARSE:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if _REHEARSE:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     return rank, local_rank, world, torch, dist
 
 
 def max_over_ranks(torch, dist, value):
     if dist is None:
         return value
-    tt = torch.tensor([value], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([value], dtype=torch.float64, device="cpu" if _REHEARSE else "cuda")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
 
@@ -280,7 +293,7 @@ def quantiles_ms(ts):
 
 # ------------------------------------------------------------------------------------------------ EKF headline
 def ekf_main(args):
-    rank, local_rank, world, torch, dist = dist_setup()
+    rank, local_rank, world, torch, dist = dist_setup(args)
     dtype = np.float32 if args.dtype == "f32" else np.float64
     N = args.landmarks or 5000
 
@@ -561,7 +574,7 @@ def _observe(w, t):
 def mc_main(args):
     """BASELINE configs[4]: independent Monte-Carlo EKF runs x 2 000 landmarks, `--instances` per GPU, one stream pair
     and one host thread per run (cslam_ekf_run_many); aggregate update steps/s."""
-    rank, local_rank, world, torch, dist = dist_setup()
+    rank, local_rank, world, torch, dist = dist_setup(args)
     import ctypes as C
 
     import conan_slam_amd
@@ -723,7 +736,7 @@ def pf_main(args):
     """BASELINE configs[3]: Np particles x Nf features, particles block-partitioned over the ranks (strong scaling:
     the particle count is fixed).  A step = predict + sampleProposal + featureUpdate + resampleParticles
     (PF.cpp:419-471, 502-544, 222-277, 473-500); the resample collectives run over torch.distributed (RCCL)."""
-    rank, local_rank, world, torch, dist = dist_setup()
+    rank, local_rank, world, torch, dist = dist_setup(args)
     from conan_slam_amd.pf import ParticleShard, SingleComm, TorchComm, resample_particles
     from conan_slam_amd.synth import Workload, normal, uniform01
 

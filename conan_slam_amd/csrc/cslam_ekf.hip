@@ -311,6 +311,10 @@ struct Ekf : EkfBase
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_mfma_f64<32>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_downdate_f64<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_downdate_f64<2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         if (getenv("CSLAM_PSYM_STAMPS"))
         {
@@ -1975,8 +1979,31 @@ template <>
 int Ekf<double>::launch_downdate(const double* W, int k, hipStream_t stream)
 {
     const int tiles_r = round_up(n, kTile) / kTile;
-    const int tiles_c = round_up(n, kTile) / 64;
-    hipLaunchKernelGGL(ekf_downdate_f64, dim3(tiles_r * tiles_c), dim3(256), 0, stream, dP, ldp, W, ldp, k, tiles_r, lower);
+    // columns of W1 staged per pass: 16 (several workgroups per CU).  Measured at N = 1000, k = 64: 8 / 16 / 32 -> 22.8 / 21.9 /
+    // 22.9 us, 64 (the whole panel at once, 96 KB of LDS, one workgroup per CU) -> 30.5 us.  CSLAM_F64_KCM overrides.
+    int kcm = 16;
+    if (const char* e = getenv("CSLAM_F64_KCM"))
+    {
+        kcm = std::max(4, std::min(64, round_up(atoi(e), 4)));
+    }
+    // tile width: 64 columns, or 32 for small states where the launch would not fill the chip (CSLAM_F64_CB overrides)
+    int cb = (tiles_r * (round_up(n, kTile) / 64) < 4 * num_cus) ? 2 : 4;
+    if (const char* e = getenv("CSLAM_F64_CB"))
+    {
+        cb = (atoi(e) == 2) ? 2 : 4;
+    }
+    const int tiles_c = round_up(n, kTile) / (16 * cb);
+    const size_t lds  = (size_t)kcm * (128 + 16 * cb) * sizeof(double);
+    if (cb == 2)
+    {
+        hipLaunchKernelGGL(ekf_downdate_f64<2>, dim3(tiles_r * tiles_c), dim3(256), lds, stream, dP, ldp, W, ldp, k, tiles_r, lower,
+                           kcm);
+    }
+    else
+    {
+        hipLaunchKernelGGL(ekf_downdate_f64<4>, dim3(tiles_r * tiles_c), dim3(256), lds, stream, dP, ldp, W, ldp, k, tiles_r, lower,
+                           kcm);
+    }
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

@@ -1345,44 +1345,50 @@ constexpr int kDownKC64 = 16;
 
 // lower != 0: block-lower storage (see p_sym): 128 x 64 tiles that lie in 128 x 128 blocks above the block diagonal are
 // not maintained -- their workgroups leave at once, the P-GEMM then reads and writes half of P.
+// kcm: columns of W1 staged per pass (dynamic LDS = kcm * 192 doubles).  With kcm = k <= 64 the whole panel is staged
+// at once: one load phase and one barrier per tile instead of four of each (the kernel is a latency chain at N = 1000).
+// CB: 16-column blocks per workgroup tile (tile = 128 rows x 16*CB columns).  At N = 1000 the kernel is a latency chain
+// (P sits in the L2 / Infinity Cache): narrower tiles mean more workgroups in flight per CU.
+template <int CB>
 __global__ void __launch_bounds__(256, 2) ekf_downdate_f64(double* __restrict__ P, int ldp,
                                                             const double* __restrict__ W1, int ldw, int k, int tiles_r,
-                                                            int lower)
+                                                            int lower, int kcm)
 {
-    if (lower && ((int)(blockIdx.x / tiles_r) >> 1) > (int)(blockIdx.x % tiles_r))
+    constexpr int TC = 16 * CB; // tile columns
+    if (lower && (((int)(blockIdx.x / tiles_r) * TC) >> 7) > (int)(blockIdx.x % tiles_r))
     {
         return;
     }
-    __shared__ __attribute__((aligned(16))) double s_pan[kDownKC64 * (128 + 64)];
-    double* sB = s_pan;                   // [kc][128] rows
-    double* sA = s_pan + kDownKC64 * 128; // [kc][64]  columns
+    extern __shared__ __attribute__((aligned(16))) double s_pan[];
+    double* sB = s_pan;             // [kc][128] rows
+    double* sA = s_pan + kcm * 128; // [kc][TC]  columns
 
     const int tid  = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
     const int lj   = lane & 15;
     const int lq   = lane >> 4;
-    const int tj   = blockIdx.x / tiles_r; // column tile of 64
+    const int tj   = blockIdx.x / tiles_r; // column tile of TC
     const int ti   = blockIdx.x % tiles_r; // row tile of 128
     const int row0 = ti * 128;
-    const int col0 = tj * 64;
+    const int col0 = tj * TC;
 
-    f64x4 acc[2][4];
+    f64x4 acc[2][CB];
 #pragma unroll
     for (int b = 0; b < 2; b++)
     {
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++)
+        for (int cb = 0; cb < CB; cb++)
         {
             acc[b][cb] = (f64x4){0.0, 0.0, 0.0, 0.0};
         }
     }
     // the P tile is requested before the panels: its latency hides behind the panel loads and the MFMA loop
     // (it used to be loaded in the epilogue: 22-26 us per launch at N = 1000 although P sits in the L2 / Infinity Cache)
-    double2* ptr[16];
-    double2  v[16];
+    double2* ptr[4 * CB];
+    double2  v[4 * CB];
 #pragma unroll
-    for (int cb = 0; cb < 4; cb++)
+    for (int cb = 0; cb < CB; cb++)
     {
 #pragma unroll
         for (int g = 0; g < 4; g++)
@@ -1392,9 +1398,9 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate_f64(double* __restrict__ 
             v[cb * 4 + g]   = *ptr[cb * 4 + g];
         }
     }
-    for (int k0 = 0; k0 < k; k0 += kDownKC64)
+    for (int k0 = 0; k0 < k; k0 += kcm)
     {
-        const int kc = min(kDownKC64, k - k0);
+        const int kc = min(kcm, k - k0);
         if (k0 > 0)
         {
             __syncthreads();
@@ -1407,12 +1413,12 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate_f64(double* __restrict__ 
             const double* w  = W1 + (size_t)(k0 + kk) * ldw;
             *reinterpret_cast<double2*>(&sB[kk * 128 + r2]) = *reinterpret_cast<const double2*>(w + row0 + r2);
         }
-        for (int id = tid; id < kc * 32; id += 256)
+        for (int id = tid; id < kc * (TC / 2); id += 256)
         {
-            const int     kk = id >> 5;
-            const int     r2 = (id & 31) * 2;
+            const int     kk = id / (TC / 2);
+            const int     r2 = (id % (TC / 2)) * 2;
             const double* w  = W1 + (size_t)(k0 + kk) * ldw;
-            *reinterpret_cast<double2*>(&sA[kk * 64 + r2]) = *reinterpret_cast<const double2*>(w + col0 + r2);
+            *reinterpret_cast<double2*>(&sA[kk * TC + r2]) = *reinterpret_cast<const double2*>(w + col0 + r2);
         }
         __syncthreads();
         // k advances by 4 per MFMA; when kc is not a multiple of 4 (k = 2 mod 4) the tail lanes feed zeros
@@ -1423,9 +1429,9 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate_f64(double* __restrict__ 
             const double2 b   = ok ? *reinterpret_cast<const double2*>(&sB[kq * 128 + wave * 32 + 2 * lj])
                                    : make_double2(0.0, 0.0);
 #pragma unroll
-            for (int cb = 0; cb < 4; cb++)
+            for (int cb = 0; cb < CB; cb++)
             {
-                const double a = ok ? sA[kq * 64 + cb * 16 + lj] : 0.0;
+                const double a = ok ? sA[kq * TC + cb * 16 + lj] : 0.0;
                 acc[0][cb]     = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.x, acc[0][cb], 0, 0, 0);
                 acc[1][cb]     = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.y, acc[1][cb], 0, 0, 0);
             }
@@ -1433,7 +1439,7 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate_f64(double* __restrict__ 
     }
     {
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++)
+        for (int cb = 0; cb < CB; cb++)
         {
 #pragma unroll
             for (int g = 0; g < 4; g++)
