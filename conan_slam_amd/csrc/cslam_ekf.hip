@@ -304,6 +304,8 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_par_kernel<T, 128>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_mfma_big_f32<128>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         else
         {
@@ -387,7 +389,7 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipMalloc(&dSub, (size_t)(3 + 64) * 64 * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dL, (size_t)64 * 64 * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dRdiag, (size_t)64 * sizeof(T)));
-            CSLAM_HIP_TRY(hipMalloc(&dM, (size_t)3 * 64 * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dM, (size_t)3 * 128 * sizeof(T)));
         }
         CSLAM_HIP_TRY(hipMalloc(&dGt, kk));
         CSLAM_HIP_TRY(hipMalloc(&dScrS, kk));
@@ -1037,6 +1039,31 @@ struct Ekf : EkfBase
         a.pred_out = dPred;
         a.lds_S    = 1;
         a.lds_G    = 1;
+        if constexpr (std::is_same<T, float>::value)
+        {
+            // 64 < k <= 128 (33..64 observations in one batch): the MFMA factor kernel with four 32-wide blocks
+            if (k > 64 && k <= 128 && tune_factor == 0)
+            {
+                constexpr int K = 128;
+                const size_t  lds = (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(float) +
+                                   (size_t)(K / 2 + 4) * sizeof(int) + 16;
+                a.dM      = dM;
+                m_valid   = (tune_gain == 0);
+                g_from_gt = true;
+                hipLaunchKernelGGL((ekf_factor_mfma_big_f32<128>), dim3(1), dim3(256), lds, stream, a, dU);
+                CSLAM_HIP_TRY(hipGetLastError());
+                if (dStamps && stamp_prints < 3)
+                {
+                    long long h[16];
+                    CSLAM_HIP_TRY(hipMemcpyAsync(h, dStamps, sizeof(h), hipMemcpyDeviceToHost, stream));
+                    CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+                    fprintf(stderr, "[cslam factor stamps k<=128, cycles] load+observe:%lld sums:%lld symmetrise+Tload:%lld cholesky:%lld inverse tail:%lld G^T:%lld t/u/M:%lld total:%lld\n",
+                            h[6] - h[0], h[7] - h[6], h[1] - h[7], h[2] - h[1], h[3] - h[2], h[9] - h[8], h[4] - h[9], h[4] - h[0]);
+                    stamp_prints++;
+                }
+                return CSLAM_OK;
+            }
+        }
         {
             // workgroup-parallel factorisation (ekf_kernels_fast.hpp); K = 128 only fits LDS in f32
             const int    kmaxp = (sizeof(T) == 4) ? 128 : 64;

@@ -911,6 +911,18 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
 // lower one); R is lower triangular: tiles I >= J.  Same inputs / outputs / flags as ekf_factor_small_kernel; dM is
 // produced as in ekf_factor_mfma_f32.  LDS (dynamic): S | sub (later: the L columns) | small arrays.
 // ------------------------------------------------------------------------------------------------
+// compile-time loop: the index is an integral_constant, so register arrays indexed with it never fall back to scratch
+// memory when the optimiser declines to unroll a large `#pragma unroll` loop
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E)
+    {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 __device__ inline double rsqrt_f64(double d)
 {
     double       y = __builtin_amdgcn_rsq(d); // ~26 bits
@@ -1353,6 +1365,428 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
                 {
                     a.dM[(vec - 1) * k + o] = s2;
                 }
+            }
+        }
+    }
+    stamp(4);
+    if (tid == 0)
+    {
+        const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
+        a.flags[1]     = code;
+        if (code)
+        {
+            atomicOr(&a.flags[0], code);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2+K3 (f32) for 64 < k <= 128 on v_mfma_f32_32x32x2_f32: the structure of ekf_factor_mfma_f64 (upper tiles only,
+// block-row updates at once, the tiles below a block four... here SIXTEEN pairs of columns per block and two columns
+// per MFMA, the inverse on a second wave one block behind) with 32 x 32 tiles: NB = K/32 = 4 blocks, 10 tiles of 16
+// VGPRs.  Tile element r of lane l = M[32 I + (r&3) + 8 (r>>2) + 4 (l>>5)][32 J + (l&31)]; row jj of a tile sits in
+// register (jj&3) + 4 (jj>>3) of the lanes with l>>5 == (jj>>2)&1.  Batches of 33..64 observations used to fall back to
+// the workgroup-parallel kernel (ekf_factor_par_kernel<float, 128>).  LDS (dynamic, 139 KB): S | sub / L | small arrays.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256) ekf_factor_mfma_big_f32(FactorArgs<float> a, float* __restrict__ du)
+{
+    static_assert(K == 64 || K == 128, "two or four 32-wide tiles per dimension");
+    typedef float T;
+    constexpr int NB = K / 32;
+    constexpr int LD = K + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_big[];
+    T*   S    = reinterpret_cast<T*>(smem_big);
+    T*   sub  = S + K * LD;
+    T*   Lm   = sub;
+    T*   coef = sub + (3 + K) * LD;
+    T*   V    = coef + (K / 2) * 10;
+    T*   rd   = V + K;
+    T*   t4   = rd + K;
+    int* fxs  = reinterpret_cast<int*>(t4 + 4 * K);
+    int* sflg = fxs + K / 2;
+    const int k   = 2 * a.m;
+    const int tid = threadIdx.x;
+    auto stamp = [&](int i) {
+        if (a.stamps && tid == 0)
+        {
+            a.stamps[i] = (long long)__builtin_readcyclecounter();
+        }
+    };
+    stamp(0);
+    const T   r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3];
+    if (tid == 0)
+    {
+        sflg[0] = 0;
+        sflg[1] = 0;
+        sflg[2] = 0;
+    }
+    if (tid < K)
+    {
+        V[tid] = (T)0;
+    }
+    __syncthreads();
+    for (int o = tid; o < a.m; o += 256)
+    {
+        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        a.dV[2 * o]     = V[2 * o];
+        a.dV[2 * o + 1] = V[2 * o + 1];
+    }
+    __syncthreads();
+    // the rows of PHT that H touches (rows 0..2, then the two rows of every observed landmark), straight from PHT:
+    // consecutive threads walk down one column
+    for (int e0 = 0; e0 < (3 + k) * k; e0 += 256 * 24)
+    {
+        T v8[24];
+#pragma unroll
+        for (int u = 0; u < 24; u++)
+        {
+            const int e  = e0 + u * 256 + tid;
+            const int ec = (e < (3 + k) * k) ? e : 0;
+            const int c = ec / (3 + k), slot = ec - c * (3 + k);
+            const int row = (slot < 3) ? slot : fxs[(slot - 3) >> 1] + ((slot - 3) & 1);
+            v8[u]         = a.PHT[(size_t)c * a.ldw + row];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; u++)
+        {
+            const int e = e0 + u * 256 + tid;
+            if (e < (3 + k) * k)
+            {
+                const int c = e / (3 + k), slot = e - c * (3 + k);
+                sub[slot * LD + c] = v8[u];
+            }
+        }
+    }
+    __syncthreads();
+    stamp(6);
+    // S = H*PHT + RR (slam.h:244): 5-term sums in ascending column order; identity padding
+#pragma unroll 8
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int r = e & (K - 1), c = e / K;
+        T         v;
+        if (r < k && c < k)
+        {
+            const int ob = r >> 1, ra = r & 1;
+            const T*  cf = &coef[ob * 10 + ra * 5];
+            T         sm = cf[0] * sub[0 * LD + c];
+            sm += cf[1] * sub[1 * LD + c];
+            sm += cf[2] * sub[2 * LD + c];
+            sm += cf[3] * sub[(3 + 2 * ob) * LD + c];
+            sm += cf[4] * sub[(4 + 2 * ob) * LD + c];
+            const int ri = ra + 2 * (c & 1);
+            const T   rv = (ri == 0) ? r00 : ((ri == 1) ? r10 : ((ri == 2) ? r01 : r11));
+            v            = sm + (((c >> 1) == ob) ? rv : (T)0);
+        }
+        else
+        {
+            v = (r == c) ? (T)1 : (T)0;
+        }
+        S[r + c * LD] = v;
+    }
+    __syncthreads();
+    stamp(7);
+    // makeSymmetric (slam.h:776-779): every thread reads (r, c) and (c, r) of ALL its elements, then all write
+    {
+        constexpr int NE = K * K / 256;
+        T             sv[NE];
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1), c = e / K;
+            const T   x = S[r + c * LD], y = S[c + r * LD];
+            sv[it]      = (r > c) ? (x + y) * (T)0.5 : ((r < c) ? (y + x) * (T)0.5 : (x + x) * (T)0.5);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NE; it++)
+        {
+            const int e = tid + it * 256;
+            const int r = e & (K - 1), c = e / K;
+            S[r + c * LD] = sv[it];
+            if (r < k && c < k)
+            {
+                a.dS[r + c * k] = sv[it];
+            }
+        }
+    }
+    for (int e = tid; e < 3 * K; e += 256) // pose rows of PHT for M, before sub becomes the L store
+    {
+        const int c = e / K, q = e - c * K;
+        t4[(1 + c) * K + q] = (q < k) ? sub[c * LD + q] : (T)0;
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int lj = lane & 31, lh = lane >> 5;
+    f32x16    Tt[NB][NB];
+    if (tid < 64)
+    {
+#pragma unroll
+        for (int I = 0; I < NB; I++)
+        {
+#pragma unroll
+            for (int J = I; J < NB; J++)
+            {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    Tt[I][J][r] = S[(32 * I + (r & 3) + 8 * (r >> 2) + 4 * lh) + (32 * J + lj) * LD];
+                }
+            }
+        }
+    }
+    else
+    {
+        for (int e = tid - 64; e < K * LD; e += 192)
+        {
+            Lm[e] = (T)0;
+        }
+    }
+    __syncthreads(); // #A
+    stamp(1);
+    bool failed = false;
+    if (tid < 64)
+    {
+        static_for<0, NB>([&](auto Jt) {
+            constexpr int J = decltype(Jt)::value;
+            T A4[NB][16]; // per block row I > J: the block's 32 columns, two per entry (the pair shares a register index)
+#pragma unroll
+            for (int I = 0; I < NB; I++)
+            {
+#pragma unroll
+                for (int t = 0; t < 16; t++)
+                {
+                    A4[I][t] = (T)0;
+                }
+            }
+            static_for<0, 32>([&](auto jt) {
+                constexpr int jj = decltype(jt)::value;
+                constexpr int j  = 32 * J + jj;
+                constexpr int rg = (jj & 3) + 4 * (jj >> 3), hf = (jj >> 2) & 1;
+                const T    dj = bcast(Tt[J][J][rg], 32 * hf + jj);
+                failed        = failed || !(dj > (T)0);
+                const T    rs = pivot_rsqrt(dj);
+                const bool on = (lh == hf);
+                T          av[NB];
+#pragma unroll
+                for (int Jc = J; Jc < NB; Jc++)
+                {
+                    const bool keep = on && (Jc > J || lj >= jj);
+                    av[Jc]          = keep ? Tt[J][Jc][rg] * rs : (T)0; // L[32 Jc + lj][j]
+                    if (on)
+                    {
+                        Lm[(32 * Jc + lj) + j * LD] = av[Jc];
+                    }
+                    if (Jc > J)
+                    {
+                        A4[Jc][rg] += av[Jc];
+                    }
+                }
+                if (lane == 0)
+                {
+                    rd[j] = rs;
+                }
+                if (jj < 31)
+                {
+#pragma unroll
+                    for (int Jc = J; Jc < NB; Jc++)
+                    {
+                        Tt[J][Jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[J], av[Jc], Tt[J][Jc], 0, 0, 0);
+                    }
+                }
+            });
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (lane == 0)
+            {
+                __hip_atomic_store(&sflg[2], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int I = J + 1; I < NB; I++)
+            {
+#pragma unroll
+                for (int Jc = I; Jc < NB; Jc++)
+                {
+#pragma unroll
+                    for (int t = 0; t < 16; t++)
+                    {
+                        Tt[I][Jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(-A4[I][t], A4[Jc][t], Tt[I][Jc], 0, 0, 0);
+                    }
+                }
+            }
+        });
+    }
+    if (tid == 0)
+    {
+        sflg[0] = failed ? 1 : 0;
+        stamp(2);
+    }
+    T chk = (T)0;
+    if (tid >= 64 && tid < 128) // ---- wave 1: the inverse, one 32-column block behind
+    {
+        for (int e = lane; e < K * LD; e += 64)
+        {
+            S[e] = (T)0;
+        }
+        const int sq = a.textbook ? LD : 1, sc = a.textbook ? 1 : LD; // X[q][c] -> S[q*sq + c*sc]
+#pragma unroll
+        for (int I = 0; I < NB; I++)
+        {
+#pragma unroll
+            for (int J = 0; J <= I; J++)
+            {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    Tt[I][J][r] = (I == J && ((r & 3) + 8 * (r >> 2) + 4 * lh) == lj) ? (T)1 : (T)0;
+                }
+            }
+        }
+        static_for<0, NB>([&](auto Qt) {
+            constexpr int Q = decltype(Qt)::value;
+            while (__hip_atomic_load(&sflg[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= Q)
+            {
+                __builtin_amdgcn_s_sleep(2);
+            }
+            T X4[NB][16];
+#pragma unroll
+            for (int Jc = 0; Jc < NB; Jc++)
+            {
+#pragma unroll
+                for (int t = 0; t < 16; t++)
+                {
+                    X4[Jc][t] = (T)0;
+                }
+            }
+            T rsv[32], lqv[32];
+#pragma unroll
+            for (int qq = 0; qq < 32; qq++)
+            {
+                rsv[qq] = rd[32 * Q + qq];
+                lqv[qq] = Lm[(32 * Q + lj) + (32 * Q + qq) * LD];
+            }
+            static_for<0, 32>([&](auto qt) {
+                constexpr int qq = decltype(qt)::value;
+                constexpr int q  = 32 * Q + qq;
+                constexpr int rg = (qq & 3) + 4 * (qq >> 3), hf = (qq >> 2) & 1;
+                const bool on = (lh == hf);
+                const T    rs = rsv[qq];
+                const T    lq_ = on ? lqv[qq] : (T)0;
+                T          xv[NB];
+#pragma unroll
+                for (int Jc = 0; Jc <= Q; Jc++)
+                {
+                    xv[Jc] = on ? Tt[Q][Jc][rg] * rs : (T)0; // X[q][32 Jc + lj]
+                    chk    = __builtin_fmaf(xv[Jc], (T)0, chk);
+                    if (on)
+                    {
+                        S[q * sq + (32 * Jc + lj) * sc] = xv[Jc];
+                    }
+                    X4[Jc][rg] += xv[Jc];
+                }
+                if (qq < 31)
+                {
+#pragma unroll
+                    for (int Jc = 0; Jc <= Q; Jc++)
+                    {
+                        Tt[Q][Jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(-lq_, xv[Jc], Tt[Q][Jc], 0, 0, 0);
+                    }
+                }
+            });
+#pragma unroll
+            for (int I = Q + 1; I < NB; I++)
+            {
+#pragma unroll
+                for (int t = 0; t < 16; t++)
+                {
+                    // group t = the two columns whose row register is t: qq = (t&3) + 8 (t>>2) + 4 lh
+                    const T li = Lm[(32 * I + lj) + (32 * Q + (t & 3) + 8 * (t >> 2) + 4 * lh) * LD];
+#pragma unroll
+                    for (int Jc = 0; Jc <= Q; Jc++)
+                    {
+                        Tt[I][Jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(-li, X4[Jc][t], Tt[I][Jc], 0, 0, 0);
+                    }
+                }
+            }
+        });
+        const bool bad = (__ballot(!(chk == chk)) != 0ull);
+        if (lane == 0)
+        {
+            sflg[1] = bad ? 1 : 0;
+        }
+    }
+    __syncthreads(); // #C
+    stamp(3);
+    stamp(8);
+    if (tid == 0 && sflg[0])
+    {
+        sflg[1] = 0;
+    }
+    __syncthreads();
+    const bool zero = (sflg[0] | sflg[1]) != 0;
+    if (zero)
+    {
+        for (int e = tid; e < K * LD; e += 256)
+        {
+            S[e] = (T)0;
+        }
+        __syncthreads();
+    }
+    // outputs: G^T (what the gain kernel reads), t = G^T V, u = G t, M
+#pragma unroll 8
+    for (int e = tid; e < K * K; e += 256)
+    {
+        const int c = e & (K - 1), r = e / K;
+        if (r < k && c < k)
+        {
+            a.dGt[c + r * k] = S[r + c * LD];
+        }
+    }
+    stamp(9);
+    for (int vec = 0; vec < 4; vec++) // (K = 128: two outputs per thread pair: 256 threads = 128 outputs x 2 parts)
+    {
+        const int o = tid >> 1, part = tid & 1;
+        const T*  vin = (vec == 0) ? V : &t4[vec * K];
+        T         s1 = (T)0;
+        if (o < K)
+        {
+#pragma unroll 16
+            for (int r = part; r < K; r += 2)
+            {
+                s1 += S[r + o * LD] * vin[r];
+            }
+        }
+        s1 += __shfl_xor(s1, 1);
+        __syncthreads();
+        if (part == 0 && o < K)
+        {
+            t4[vec * K + o] = (o < k) ? s1 : (T)0;
+            if (vec == 0 && o < k)
+            {
+                a.dt[o] = s1;
+            }
+        }
+        __syncthreads();
+        T s2 = (T)0;
+        if (o < K)
+        {
+#pragma unroll 16
+            for (int c = part; c < K; c += 2)
+            {
+                s2 += S[o + c * LD] * t4[vec * K + c];
+            }
+        }
+        s2 += __shfl_xor(s2, 1);
+        if (part == 0 && o < k)
+        {
+            if (vec == 0)
+            {
+                du[o] = s2;
+            }
+            else if (a.dM != nullptr)
+            {
+                a.dM[(vec - 1) * k + o] = s2;
             }
         }
     }

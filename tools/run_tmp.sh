@@ -1,11 +1,9 @@
 R=$GRAFT_REPO_ROOT
 cd $R
-for cb in 4 2; do
-CSLAM_F64_CB=$cb python3 bench.py --dtype f64 --landmarks 1000 --steps 400 --no-cpu-baseline --no-extras > gpurun_out/r2_f64_9.json 2>gpurun_out/r2_f64_9.err
+CSLAM_FACTOR_STAMPS=1 python3 bench.py --obs 64 --defer 0 --steps 100 --no-cpu-baseline --no-extras --stage-profile > gpurun_out/r2_b11.json 2> gpurun_out/r2_b11.err
+grep stamps gpurun_out/r2_b11.err | head -2
 python3 -c "
-import json;d=json.load(open('gpurun_out/r2_f64_9.json'))
-print('f64 cb=$cb', round(d['value']), d['ms_per_step'], d['roofline']['launch_us'])
+import json;d=json.load(open('gpurun_out/r2_b11.json'))
+print('m=64 k=128', round(d['value']), d['ms_per_step'], d.get('stage_us'), d['factor_flags'])
 "
-done
-python -m pytest tests -q -m gpu -x -k "f64 or float64 or config1 or golden or deferred or sequential" > gpurun_out/r2_t18.log 2>&1; echo "tests rc=$?"
-tail -2 gpurun_out/r2_t18.log
+python -m pytest tests/test_ekf_gpu.py -q -m gpu -x -k "batch_update" 2>&1 | tail -2
