@@ -51,7 +51,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--workload", choices=["ekf", "mc", "pf"], default="ekf")
     ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=1500,
+                    help="untimed steps before the timed region.  The default is long on purpose: the asynchronous loop lets "
+                         "the host run hundreds of steps ahead of the GPU, and the first time the backlog passes ~2-3 thousand "
+                         "launches the HIP runtime stalls the enqueueing thread once for 30-60 ms while the GPU idles "
+                         "(tools/drift_probe.py; f64 N=1000: warm-up 20/400/1000 + 1000 steps -> 80 / 123 / 68.7 us per "
+                         "step).  A long warm-up gets that one-time event out of the way")
     ap.add_argument("--landmarks", type=int, default=None, help="default 5000 (ekf) / 2000 (mc)")
     ap.add_argument("--obs", type=int, default=32, help="observations per batch update (k = 2*obs)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")

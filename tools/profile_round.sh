@@ -8,11 +8,15 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$(echo $c | tr ' ' '_')
-  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -o runc -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extras > $O/pmc_$d.log 2>&1
+  # headline (deferred 128: k = 128 launches) and immediate (k = 64 launches), separate passes per counter set
+  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/k128_$d -o runc -- python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extras > $O/pmc_k128_$d.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/k64_$d -o runc -- python3 $R/bench.py --defer 0 --steps 12 --warmup 3 --no-cpu-baseline --no-extras > $O/pmc_k64_$d.log 2>&1
   echo "pmc $d done"
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ekf -o run -- python3 $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-extras > $O/stats_ekf.log 2>&1
 echo "stats ekf done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ekf_immediate -o run -- python3 $R/bench.py --defer 0 --steps 200 --warmup 10 --no-cpu-baseline --no-extras > $O/stats_ekf_immediate.log 2>&1
+echo "stats ekf immediate done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f64 -o run -- python3 $R/bench.py --dtype f64 --landmarks 1000 --steps 200 --warmup 10 --no-cpu-baseline --no-extras > $O/stats_f64.log 2>&1
 echo "stats f64 done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pf -o run -- python3 $R/bench.py --workload pf --steps 200 --warmup 10 --force-resample --no-cpu-baseline > $O/stats_pf.log 2>&1
@@ -28,7 +32,7 @@ python3 bench.py --dtype f64 --landmarks 1000 --stage-profile > $O/bench_f64_n10
 python3 bench.py --workload pf --force-resample > $O/bench_pf.json 2>> $O/bench.err || true
 python3 bench.py --workload mc --pgemm-wgs 0 > $O/bench_mc.json 2>> $O/bench.err || true
 python3 bench.py --sequential --obs 8 --no-cpu-baseline --no-extras > $O/bench_sequential.json 2>> $O/bench.err || true
-python3 bench.py --defer 128 --no-cpu-baseline --no-extras > $O/bench_deferred128.json 2>> $O/bench.err || true
+python3 bench.py --obs 64 --defer 0 --no-cpu-baseline --no-extras --stage-profile > $O/bench_m64.json 2>> $O/bench.err || true
 CSLAM_PIPELINE=1 python3 bench.py --no-cpu-baseline --no-extras > $O/bench_pipelined.json 2>> $O/bench.err || true
 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2>> $O/bench.err || true
 tail -c 400 $O/bench_ekf.json

@@ -1,9 +1,8 @@
 R=$GRAFT_REPO_ROOT
 cd $R
-CSLAM_FACTOR_STAMPS=1 python3 bench.py --obs 64 --defer 0 --steps 100 --no-cpu-baseline --no-extras --stage-profile > gpurun_out/r2_b11.json 2> gpurun_out/r2_b11.err
-grep stamps gpurun_out/r2_b11.err | head -2
+for cfg in "20 400" "400 400" "400 1000" "20 1000" "1000 1000"; do
+set -- $cfg
+python3 bench.py --dtype f64 --landmarks 1000 --warmup $1 --steps $2 --no-cpu-baseline --no-extras > gpurun_out/r2_f64_11.json 2>gpurun_out/r2_f64_11.err || tail -3 gpurun_out/r2_f64_11.err
 python3 -c "
-import json;d=json.load(open('gpurun_out/r2_b11.json'))
-print('m=64 k=128', round(d['value']), d['ms_per_step'], d.get('stage_us'), d['factor_flags'])
-"
-python -m pytest tests/test_ekf_gpu.py -q -m gpu -x -k "batch_update" 2>&1 | tail -2
+import json;d=json.load(open('gpurun_out/r2_f64_11.json'));print('f64 warmup $1 steps $2:', round(d['value']), round(d['ms_per_step']*1e3,1), 'us/step, P-GEMM', round(d['roofline']['launch_us'],1), d['roofline']['launches_timed'])"
+done
