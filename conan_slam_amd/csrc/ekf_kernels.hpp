@@ -13,8 +13,8 @@
 //   ekf_factor_kernel    S = H*PHT+R, symmetrise, LLT, G = inv(L) or inv(L)^T, t = G^T V (slam.h:244-255, EKF.cpp:108-121)
 //   ekf_gain_kernel      W1 = PHT*G, X += W1*t                                       (slam.h:257-259)
 //   ekf_downdate_f32/f64 P -= W1*W1^T on MFMA, LDS-tiled                             (slam.h:260)
-//   ekf_predict_kernel   EKF.cpp:406-455        ekf_augment_kernel   EKF.cpp:28-91
-//   ekf_heading_*        EKF.cpp:328-352 + slam.h:700-725 in exact rank-structured form
+//   (predict, heading, augment and the pose-stripe downdate: ekf_pose_kernels.hpp; the tuned factor / gain / P-GEMM
+//    kernels: ekf_kernels_fast.hpp)
 #pragma once
 
 #include <hip/hip_runtime.h>
