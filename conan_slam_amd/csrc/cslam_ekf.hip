@@ -1,15 +1,16 @@
 // cslam_ekf.hip -- host side of the EKF-SLAM engine behind the C ABI of include/cslam.h.
 //
 // One handle = one filter instance bound to one device; X and P live in HBM for the lifetime of the handle.
-// update() is a chain of launches (gather, [pending-panel correction], factor, gain, pose-stripe downdate) on the
-// handle's stream A, and the covariance downdate P -= W1 W1^T (the P-GEMM) on stream B:
+// update() is a chain of launches on the handle's stream: gather (+ the correction for pending panels), factor, gain
+// (which also takes the pose stripe's share of the downdate), and the covariance downdate P -= W1 W1^T (the P-GEMM).
 //
-//   pipelined mode (f32 block-lower default, CSLAM_PIPELINE): the covariance is held as P = Ps - Wp Wp^T with the W1
-//   panel of the LAST update (and the rank-1 columns of heading observations since) still pending.  Update t+1 gathers
-//   its columns from Ps (corrected by the pending panel), THEN the P-GEMM of panel t starts on stream B and sweeps Ps
-//   while stream A runs the serial factor / gain chain of update t+1, predicts and heading observations (which only touch
-//   the pose stripe Pv, see ekf_kernels.hpp p_get, never Ps).  Step time = gather + P-GEMM instead of the whole chain.
-//   immediate mode: every update launches its own P-GEMM behind its gain kernel on the same stream.
+//   immediate mode (default): every update launches its own P-GEMM behind its gain kernel.
+//   deferred mode (cslam_ekf_set_deferred, and always inside a sequential update): the covariance is held as
+//     P = Ps - Wp Wp^T with up to kmax columns of W1 panels (and the rank-1 columns of heading observations) pending;
+//     readers of P correct for them, ONE P-GEMM applies them all.
+//   two-stream mode (CSLAM_PIPELINE=1, an experiment that is NOT the default: measured slower): the
+//     pending columns' P-GEMM runs on a second stream underneath the next update's factor / gain chain.  What makes it
+//     legal is the pose stripe Pv (ekf_kernels.hpp p_get): predicts and heading observations never touch Ps.
 // Nothing returns to the host unless the caller asks (get_x / get_state / sync mode).
 #include <hip/hip_runtime.h>
 
