@@ -997,6 +997,8 @@ struct Pf : PfBase
             std::memcpy(slot + off_normals(), normals, nb);
         }
         std::memcpy(slot + off_sel, select, (size_t)np * sizeof(T));
+        // (zero-copy -- the kernels reading the pinned slot over the host link -- was tried instead of this staged copy:
+        // 13.7 k instead of 15.0 k steps/s)
         staged.clear();
         CSLAM_HIP_TRY(hipMemcpyAsync(dObs, slot, bytes, hipMemcpyHostToDevice, stream));
         if ((rc = stage_commit()))
