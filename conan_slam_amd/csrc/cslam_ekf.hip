@@ -56,6 +56,8 @@ struct EkfBase
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     int         pipeline      = 0; // P-GEMM of update t on stream B under the chain of update t+1 (env CSLAM_PIPELINE)
     int         pgemm_spare   = 16; // pipelined: workgroups the persistent P-GEMM grid leaves out (env CSLAM_PGEMM_SPARE)
+    int         gather_corr_wide = 1; // a pending batch panel (<= 64 columns) corrected for inside the gather kernel (env CSLAM_GATHER_WIDE)
+    int         cu_split      = 0;  // pipelined: compute units reserved for the chain's stream by queue CU masks (env CSLAM_CU_SPLIT)
     int         pgemm_wgs     = 0;  // > 0: cap on the persistent P-GEMM grid (cslam_ekf_set_pgemm_workgroups: co-running instances)
     hipStream_t stream   = nullptr; // A: everything except the P-GEMM
     hipStream_t stream_b = nullptr; // B: the P-GEMM (== stream when not pipelined)
@@ -267,8 +269,29 @@ struct Ekf : EkfBase
             // the chain (A) outranks the P-GEMM (B): its small kernels must get in while the P-GEMM fills the chip
             int lo = 0, hi = 0;
             CSLAM_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
-            CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream_b, hipStreamNonBlocking, lo));
+            if (cu_split > 0)
+            {
+                // compute units partitioned between the two streams (queue CU masks): the chain's small kernels get
+                // cu_split units to themselves instead of crawling next to the P-GEMM's waves.  Mask bit i is unit
+                // i / 8 of XCD i % 8, so whole multiples of 8 take the same number of units from every XCD.
+                hipDeviceProp_t prop;
+                CSLAM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+                const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+                cu_split      = std::min(std::max(8, (cu_split / 8) * 8), cus / 2);
+                const int words = (cus + 31) / 32;
+                std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
+                for (int i = 0; i < cus; i++)
+                {
+                    (i < cus - cu_split ? mb : ma)[i / 32] |= 1u << (i % 32);
+                }
+                CSLAM_HIP_TRY(hipExtStreamCreateWithCUMask(&stream, (uint32_t)words, ma.data()));
+                CSLAM_HIP_TRY(hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)words, mb.data()));
+            }
+            else
+            {
+                CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+                CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream_b, hipStreamNonBlocking, lo));
+            }
         }
         else
         {
@@ -1264,7 +1287,9 @@ struct Ekf : EkfBase
             return rc;
         }
         // a few pending columns (heading observations) are corrected for inside the gather kernel: the fast path stays
-        const bool small_corr = kp > 0 && kp <= kGatherCorr && !pipeline;
+        // ... and so is one deferred batch panel (up to kGatherCorrMax columns), by the kernel's wider form
+        const bool small_corr = kp > 0 && kp <= (gather_corr_wide ? kGatherCorrMax : kGatherCorr) && !pipeline;
+        const bool wide_corr  = small_corr && kp > kGatherCorr;
         // a pending predict() rides along when this batch takes the (non-pipelined) fast path
         fuse_now = pp.valid && sizeof(T) == 4 && !pipeline && !keep_pending && k > 16 && k <= 64 && tune_factor == 0 &&
                    tune_gain == 0;
@@ -1307,11 +1332,28 @@ struct Ekf : EkfBase
         // the compact H-rows block for the MFMA factor kernel (f32, 16 < k <= 64, no pending panels to correct)
         sub_valid = (k > 16 && k <= 64 && (kp == 0 || small_corr) && tune_factor == 0 && dSub != nullptr);
         PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
-        hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, dPv, ldp, n, dZ, dIdf, m, dPHT, ldp,
-                           lower, sub_valid ? dSub : nullptr, fuse_now ? pp : pnone, fuse_now ? dPred : (T*)nullptr,
-                           (kp > 0 && !pipeline) ? (const T*)wbase(wcur) : (const T*)nullptr, ldp, pipeline ? 0 : kp,
-                           (kp > 0 && !pipeline && hd_cols[wcur] > 0) ? dSign + (size_t)wcur * wcap : (const int*)nullptr, dFlags,
-                           (kp > 0 && !small_corr && !pipeline) ? dY : (T*)nullptr);
+        {
+            T*             sub  = sub_valid ? dSub : nullptr;
+            PredictArgs<T> pa   = fuse_now ? pp : pnone;
+            T*             pred = fuse_now ? dPred : (T*)nullptr;
+            const T*       Wg   = (kp > 0 && !pipeline) ? (const T*)wbase(wcur) : (const T*)nullptr;
+            const int      kg   = pipeline ? 0 : kp;
+            const int*     sg =
+                (kp > 0 && !pipeline && hd_cols[wcur] > 0) ? dSign + (size_t)wcur * wcap : (const int*)nullptr;
+            T* yout = (kp > 0 && !small_corr && !pipeline) ? dY : (T*)nullptr;
+            if (wide_corr)
+            {
+                const dim3 wgrid((n + 255) / 256, (m + kGatherObsWide - 1) / kGatherObsWide);
+                hipLaunchKernelGGL((ekf_gather_kernel<T, kGatherCorrMax, kGatherObsWide>), wgrid, dim3(256), 0, stream, dX,
+                                   dP, dPv, ldp, n, dZ, dIdf, m, dPHT, ldp, lower, sub, pa, pred, Wg, ldp, kg, sg, dFlags,
+                                   yout);
+            }
+            else
+            {
+                hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, dPv, ldp, n, dZ, dIdf, m, dPHT,
+                                   ldp, lower, sub, pa, pred, Wg, ldp, kg, sg, dFlags, yout);
+            }
+        }
         CSLAM_HIP_TRY(hipGetLastError());
         // the panels this update's P*H^T must be corrected with, and where its own W1 goes
         const T*  Wc        = wbase(wcur);
@@ -1781,6 +1823,10 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
         // so that the one-workgroup factor kernel of the NEXT update (53 KB LDS, stream A) finds room while this P-GEMM
         // fills the chip (pipelined mode).
         int G = std::min(n_sym_tiles, std::max(1, 2 * num_cus - (pipeline ? pgemm_spare : 0)));
+        if (pipeline && cu_split > 0 && stream != this->stream)
+        {
+            G = std::min(n_sym_tiles, 2 * (num_cus - cu_split)); // its stream owns that many compute units
+        }
         if (pgemm_wgs > 0)
         {
             G = std::min(G, pgemm_wgs);
@@ -2161,6 +2207,14 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* pv = getenv("CSLAM_PIPELINE"))
     {
         b->pipeline = atoi(pv) ? 1 : 0;
+    }
+    if (const char* gw = getenv("CSLAM_GATHER_WIDE"))
+    {
+        b->gather_corr_wide = atoi(gw) ? 1 : 0;
+    }
+    if (const char* cs = getenv("CSLAM_CU_SPLIT"))
+    {
+        b->cu_split = std::max(0, atoi(cs));
     }
     if (const char* sp = getenv("CSLAM_PGEMM_SPARE"))
     {

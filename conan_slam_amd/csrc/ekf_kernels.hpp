@@ -250,10 +250,12 @@ __device__ inline void predict_pvv(const PredictArgs<T>& pp, T phi_old, const T*
 // (EKF.cpp:394-395), which in column-major P are contiguous columns -> fully coalesced reads.
 // grid = (ceil(n/256), ceil(m/kGatherObs)), block = 256.
 // ------------------------------------------------------------------------------------------------
-constexpr int kGatherCorr = 16; // pending columns the gather kernel corrects for by itself
+constexpr int kGatherCorr = 16; // pending columns the gather kernel corrects for by itself (its template default)
+constexpr int kGatherCorrMax = 64; // ... and its <T, 64, kGatherObsWide> form: one deferred batch panel (m <= 32)
+constexpr int kGatherObsWide = 2;  // observations per workgroup of that form (each workgroup reads its rows of the panel)
 constexpr int kGatherObs = 1; // measured at N = 5000, m = 32: 11.1 us (8 per block), 10.2 (4), 9.5 (2), 8.7 (1): the kernel is a latency chain, more blocks win
 
-template <typename T>
+template <typename T, int KC = kGatherCorr, int OBS = kGatherObs>
 __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X, const T* __restrict__ P,
                                                           const T* __restrict__ Pv, int ldp,
                                                           int n, const T* __restrict__ Z, const int* __restrict__ idf,
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
                                                           int* __restrict__ flags = nullptr,
                                                           T* __restrict__ Yout = nullptr)
 {
-    // Yout (kc > kGatherCorr): the pending panels are too many to correct for here: this kernel only publishes
+    // Yout (kc > KC, the template bound): the pending panels are too many to correct for here: this kernel only publishes
     // Y = H*Wc (k x kc, Y[q*k + row]) -- with the coefficients of the (possibly predicted) pose it has anyway -- and the
     // MFMA panel kernel applies PHT -= Wc*Y^T behind it.
     if (flags != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < m)
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
             atomicOr(&flags[0], kFlagBadIdf);
         }
     }
-    // Wc / kc (kc <= kGatherCorr): a FEW pending columns (heading observations: rank-1 columns, ekf_pose_step_kernel)
+    // Wc / kc (kc <= KC): a FEW pending columns (heading observations: rank-1 columns, ekf_pose_step_kernel)
     // are corrected for right here -- PHT = Ps*H^T - Wc*(H*Wc)^T with H*Wc built per workgroup from the two landmark
     // rows of Wc (its pose rows are zero) -- so that the update keeps its fast path (compact block, fused predict)
     // instead of going through the separate correction kernels.
@@ -287,11 +289,11 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     // sub (optional, m <= 32): the (3 + 2m) x 2m block of PHT that S = H*PHT reads -- rows 0,1,2 and the two rows
     // of every observed landmark -- stored compactly as sub[slot*2m + col] (slot 3+2o+a <-> row fx_o + a), so that
     // the one-workgroup factor kernel loads 17 KB of contiguous data instead of 2000 scattered cache lines.
-    __shared__ T   s_coef[kGatherObs * 10];
-    __shared__ int s_fx[kGatherObs];
+    __shared__ T   s_coef[OBS * 10];
+    __shared__ int s_fx[OBS];
     __shared__ int s_idf[32];
-    int            o0 = blockIdx.y * kGatherObs;
-    int            no = min(kGatherObs, m - o0);
+    int            o0 = blockIdx.y * OBS;
+    int            no = min(OBS, m - o0);
     __shared__ unsigned s_cand; // observations whose landmark rows fall into this block's 256 rows
     if (sub != nullptr && threadIdx.x == 0)
     {
@@ -302,26 +304,36 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     // instead of one after the other (the kernel is a chain of dependent round trips, nothing else).
     const int i  = blockIdx.x * 256 + threadIdx.x;
     const int il = min(i, n - 1); // (rows past n: clamped loads, no stores)
-    int       fxe[kGatherObs];
-    T         ea[kGatherObs], eb[kGatherObs];
-    T         sa[kGatherObs][3], sb[kGatherObs][3]; // pp.valid, i < 3: rows 0..2 of the landmark's two columns
+    int       fxe[OBS];
+    T         ea[OBS], eb[OBS];
+    T         sa[OBS][3], sb[OBS][3]; // pp.valid, i < 3: rows 0..2 of the landmark's two columns
     T         Pvv[9];
     const T   phi_old = X[2];
 #pragma unroll
-    for (int oo = 0; oo < kGatherObs; oo++)
+    for (int oo = 0; oo < OBS; oo++)
     {
         fxe[oo] = 3 + 2 * clamp_idf(idf[o0 + min(oo, no - 1)], n) - 2; // as observe_model_pose
         ea[oo]  = p_get<T>(P, Pv, ldp, il, fxe[oo], lower);
         eb[oo]  = p_get<T>(P, Pv, ldp, il, fxe[oo] + 1, lower);
     }
     T p0 = Pv[(size_t)0 * ldp + il], p1 = Pv[(size_t)1 * ldp + il], p2 = Pv[(size_t)2 * ldp + il];
-    T wc[kGatherCorr];
+    T wc[KC];
 #pragma unroll
-    for (int q = 0; q < kGatherCorr; q++)
+    for (int q = 0; q < KC; q++)
     {
         wc[q] = (q < kc && Yout == nullptr) ? Wc[(size_t)q * ldwc + il] : (T)0;
     }
-    __shared__ T s_y[kGatherObs][2][kGatherCorr];
+    __shared__ T s_y[OBS][2][KC];
+    // (kc > 0, in-kernel correction) the two landmark rows of pending column q that thread (oo, q) turns into Y below:
+    // requested here with everything else (the landmark id fixes the rows)
+    T         ywa = (T)0, ywb = (T)0;
+    const int yoo = threadIdx.x / KC, yq = threadIdx.x % KC;
+    if (kc > 0 && Yout == nullptr && yoo < no && yq < kc)
+    {
+        const int fy = 3 + 2 * clamp_idf(idf[o0 + yoo], n) - 2;
+        ywa          = Wc[(size_t)yq * ldwc + fy];
+        ywb          = Wc[(size_t)yq * ldwc + fy + 1];
+    }
     if (pp.valid && i < 3)
     {
         for (int cc = 0; cc < 3; cc++)
@@ -332,7 +344,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
             }
         }
 #pragma unroll
-        for (int oo = 0; oo < kGatherObs; oo++)
+        for (int oo = 0; oo < OBS; oo++)
         {
             for (int r = 0; r < 3; r++)
             {
@@ -389,14 +401,14 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
     if (kc > 0 && Yout == nullptr) // (workgroup-uniform)
     {
         // Y = H*Wc for this workgroup's observations: only the landmark columns of H meet non-zero rows of Wc
-        if ((int)threadIdx.x < no * kGatherCorr)
+        if ((int)threadIdx.x < no * KC)
         {
-            const int oo = threadIdx.x / kGatherCorr, q = threadIdx.x % kGatherCorr;
+            const int oo = yoo, q = yq;
             T         y0 = (T)0, y1 = (T)0;
             if (q < kc)
             {
                 const T* c  = &s_coef[oo * 10];
-                const T  wa = Wc[(size_t)q * ldwc + s_fx[oo]], wb = Wc[(size_t)q * ldwc + s_fx[oo] + 1];
+                const T  wa = ywa, wb = ywb;
                 y0          = c[3] * wa;
                 y0 += c[4] * wb;
                 y1 = c[8] * wa;
@@ -469,7 +481,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         }
     }
 #pragma unroll
-    for (int oo = 0; oo < kGatherObs; oo++)
+    for (int oo = 0; oo < OBS; oo++)
     {
         if (oo >= no)
         {
@@ -508,7 +520,7 @@ __global__ void __launch_bounds__(256) ekf_gather_kernel(const T* __restrict__ X
         {
             T c0 = (T)0, c1 = (T)0;
 #pragma unroll
-            for (int q = 0; q < kGatherCorr; q++)
+            for (int q = 0; q < KC; q++)
             {
                 c0 += wc[q] * s_y[oo][0][q];
                 c1 += wc[q] * s_y[oo][1][q];
