@@ -42,6 +42,7 @@ struct EkfBase
 {
     virtual ~EkfBase() {}
     int         dtype    = CSLAM_F32;
+    int         fuse_f64 = 1; // the f64 MFMA kernels take a held predict too (env CSLAM_FUSE_F64=0: its own launch)
     int         device   = 0;
     int         quirks   = CSLAM_Q_REF_EXACT;
     int         nmax     = 0; // max landmarks
@@ -918,7 +919,7 @@ struct Ekf : EkfBase
     //                      the two back to back on every control step, test/main.cpp:165-168); up to kPoseSeqMax steps
     //                      queue up and run in ONE ekf_pose_step_kernel launch (they only touch the pose stripe Pv, X and
     //                      the pending store: see ekf_pose_kernels.hpp);
-    //   a batch update on the fast path (f32, 16 < k <= 64) applies a held predict on the fly in its gather / factor /
+    //   a batch update on the fast path (16 < k <= 64) applies a held predict on the fly in its gather / factor /
     //                      gain kernels and commits it (PredictArgs in ekf_kernels.hpp);
     //   anything else that reads X or P launches what is queued first (resolve_predict).
     // CSLAM_FUSE_PREDICT=0 launches every predict / heading at once.
@@ -1291,7 +1292,7 @@ struct Ekf : EkfBase
         const bool small_corr = kp > 0 && kp <= (gather_corr_wide ? kGatherCorrMax : kGatherCorr) && !pipeline;
         const bool wide_corr  = small_corr && kp > kGatherCorr;
         // a pending predict() rides along when this batch takes the (non-pipelined) fast path
-        fuse_now = pp.valid && sizeof(T) == 4 && !pipeline && !keep_pending && k > 16 && k <= 64 && tune_factor == 0 &&
+        fuse_now = pp.valid && (sizeof(T) == 4 || fuse_f64) && !pipeline && !keep_pending && k > 16 && k <= 64 && tune_factor == 0 &&
                    tune_gain == 0;
         if ((rc = fuse_now ? launch_pose_queue() : resolve_predict())) // (queued control steps come first either way)
         {
@@ -2044,7 +2045,8 @@ bool Ekf<double>::launch_gain_fast(int k, int n_pad, double* slot)
         return false;
     }
     hipLaunchKernelGGL((ekf_panel_mfma_f64<false, true>), dim3(n_pad / 16, (k + 15) / 16), dim3(64), 0, stream, dPHT, ldp, n, k,
-                       k, dGt, k, dU, slot, ldp, dX, dPv, ldp, m_valid ? (const double*)dM : (const double*)nullptr, dWv);
+                       k, dGt, k, dU, slot, ldp, dX, dPv, ldp, m_valid ? (const double*)dM : (const double*)nullptr, dWv,
+                       fuse_now ? (const double*)dPred : (const double*)nullptr, pp.w);
     pose_fused_in_gain = m_valid;
     return true;
 }
@@ -2175,6 +2177,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* tv = getenv("CSLAM_TUNE_DOWNDATE"))
     {
         b->tune_downdate = atoi(tv);
+    }
+    if (const char* ff = getenv("CSLAM_FUSE_F64"))
+    {
+        b->fuse_f64 = atoi(ff) ? 1 : 0;
     }
     if (const char* fp = getenv("CSLAM_FUSE_PREDICT"))
     {

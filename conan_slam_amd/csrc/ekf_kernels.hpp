@@ -865,7 +865,7 @@ struct FactorArgs
     T*         dRdiag; // 1 / diag(L), K values
     T*         dM;     // optional (ekf_factor_mfma_f32): M = G*(G^T*PHT[0:3,:]^T), 3 x k (row c at dM + c*k): the gain kernel
                        // then applies the pose-stripe downdate P[:,0:3] -= W1*W1[0:3,:]^T = PHT*M itself (see ekf_panel_mfma_f32)
-    PredictArgs<T> pp;   // pending predict (valid = 0: none); honoured by ekf_factor_mfma_f32 only
+    PredictArgs<T> pp;   // pending predict (valid = 0: none); honoured by ekf_factor_mfma_f32 / ekf_factor_mfma_f64 only
     const T*   P3;       // P (for Pvv) and its leading dimension, used with pp.valid
     int        ldp3;
     const T*   pred_out; // pp.valid: {g02, g12, predicted pose (3), predicted Pvv (9)} written by the gather kernel

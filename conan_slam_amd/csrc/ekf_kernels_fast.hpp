@@ -987,7 +987,10 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
     }
     for (int o = tid; o < a.m; o += 256)
     {
-        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
+        // the predicted pose when a predict() is pending (the gather kernel left it in pred_out), else the stored one
+        const T* ps = a.pp.valid ? (a.pred_out + 2) : a.X;
+        observe_model_pose<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], ps[0], ps[1], ps[2], &coef[o * 10], &V[2 * o],
+                              &fxs[o]);
         a.dV[2 * o]     = V[2 * o];
         a.dV[2 * o + 1] = V[2 * o + 1];
     }
@@ -2818,8 +2821,11 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f64(const double* __restric
                                                           const double* __restrict__ u, double* __restrict__ OUT, int ldo,
                                                           double* __restrict__ X, double* __restrict__ Pv = nullptr,
                                                           int ldp = 0, const double* __restrict__ Mv = nullptr,
-                                                          double* __restrict__ wv_out = nullptr)
+                                                          double* __restrict__ wv_out = nullptr,
+                                                          const double* __restrict__ pred = nullptr, int pred_w = 0)
 {
+    // pred != nullptr (gain, XUPD): commits a predict() that the gather and factor kernels applied on the fly, exactly as
+    // ekf_panel_mfma_f32 does: pred = {g02, g12, pose (3), Pvv (9)} from the gather kernel.
     const int  lane = threadIdx.x;
     const int  lj   = lane & 15;
     const int  lq   = lane >> 4;
@@ -2909,10 +2915,31 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f64(const double* __restric
         const int r = row0 + lj;
         if (lq == 0 && r < n)
         {
-            X[r] += xs;
-            if (Mv != nullptr)
+            X[r] = ((pred != nullptr && r < 3) ? pred[2 + r] : X[r]) + xs;
+            if (pred != nullptr || Mv != nullptr)
             {
-                const double a0 = Pv[(size_t)0 * ldp + r], a1 = Pv[(size_t)1 * ldp + r], a2 = Pv[(size_t)2 * ldp + r];
+                // row r of the pose stripe: [predicted (EKF.cpp:439-443)] then [downdated] (xm* are zero without Mv)
+                double a0 = Pv[(size_t)0 * ldp + r], a1 = Pv[(size_t)1 * ldp + r], a2 = Pv[(size_t)2 * ldp + r];
+                if (pred != nullptr)
+                {
+                    if (r >= 3)
+                    {
+                        if (r - 3 < pred_w)
+                        {
+                            double o0, o1, o2;
+                            predict_stripe_col<double>(pred[0], pred[1], a0, a1, a2, &o0, &o1, &o2);
+                            a0 = o0;
+                            a1 = o1;
+                            a2 = o2;
+                        }
+                    }
+                    else // the pose block: predicted Pvv, row r
+                    {
+                        a0 = pred[5 + r];
+                        a1 = pred[5 + r + 3];
+                        a2 = pred[5 + r + 6];
+                    }
+                }
                 if (r >= 3)
                 {
                     Pv[(size_t)0 * ldp + r] = a0 - xm0;
@@ -2932,7 +2959,7 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f64(const double* __restric
                         }
                         else if (c < r)
                         {
-                            const double bcr        = Pv[(size_t)r * ldp + c];
+                            const double bcr = (pred != nullptr) ? pred[5 + c + 3 * r] : Pv[(size_t)r * ldp + c]; // (c, r)
                             Pv[(size_t)c * ldp + r] = av[c] - dv[c];
                             Pv[(size_t)r * ldp + c] = bcr - dv[c];
                         }
