@@ -27,6 +27,7 @@
 #include "cslam_common.hpp"
 #include "ekf_kernels.hpp"
 #include "ekf_kernels_fast.hpp"
+#include "ekf_pgemm_limbs.hpp"
 #include "ekf_pose_kernels.hpp"
 #include "host_linalg.hpp"
 
@@ -43,6 +44,7 @@ struct EkfBase
     virtual ~EkfBase() {}
     int         dtype    = CSLAM_F32;
     int         fuse_f64 = 1; // the f64 MFMA kernels take a held predict too (env CSLAM_FUSE_F64=0: its own launch)
+    int         pgemm_limbs_req = -1, limbs_kmin_req = -1; // env CSLAM_PGEMM_LIMBS / CSLAM_LIMBS_KMIN (-1: default)
     int         device   = 0;
     int         quirks   = CSLAM_Q_REF_EXACT;
     int         nmax     = 0; // max landmarks
@@ -141,6 +143,19 @@ struct Ekf : EkfBase
     int   stamp_prints = 0;
     long long* dPsymStamps = nullptr; // CSLAM_PSYM_STAMPS=1
     int*       dTicket     = nullptr; // two tile-ticket counters used alternately by successive P-GEMM launches
+    // f32 P-GEMM on the bf16 matrix cores (ekf_pgemm_limbs.hpp): limb pairs per product (9 exact, 6, 0 = the f32 MFMA
+    // kernel; env CSLAM_PGEMM_LIMBS), from how many columns on (env CSLAM_LIMBS_KMIN), the limb store and its size.
+    // Off by default: correct and as accurate as the f32 MFMA kernel (tests), but measured no faster -- 120 - 132 us
+    // against 115 at k = 128, N = 5000 -- see DESIGN.md 8.
+    int        pgemm_limbs = 0;
+    int        limbs_kmin  = 65;
+    uint4*     dWb         = nullptr;
+    size_t     wb_bytes    = 0;
+    int2*      dTilesM     = nullptr; // the tile list in Morton order, cut into eight segments (one per XCD) ...
+    int*       dSegOff     = nullptr; // ... at these offsets (9), and two sets of eight ticket counters
+    int*       dTicketX    = nullptr;
+    int        tilesM_built = 0;
+    int        limb_parity = 0;
     unsigned   launch_parity = 0;
     int        psym_nt = -1; // CSLAM_PSYM_NT: non-temporal P accesses in the P-GEMM (-1: by footprint)
     int        psym_prefetch = -1; // CSLAM_PSYM_PREFETCH: software-pipelined LDS operands in the P-GEMM (-1: by chunk count)
@@ -206,6 +221,10 @@ struct Ekf : EkfBase
         (void)hipFree(dPsymStamps);
         (void)hipFree(dHwIds);
         (void)hipFree(dTicket);
+        (void)hipFree(dWb);
+        (void)hipFree(dTilesM);
+        (void)hipFree(dSegOff);
+        (void)hipFree(dTicketX);
         (void)hipFree(dPred);
         (void)hipFree(dAssoc);
         (void)hipFree(dAssocOut);
@@ -264,6 +283,14 @@ struct Ekf : EkfBase
         if (rc)
         {
             return rc;
+        }
+        if (pgemm_limbs_req >= 0)
+        {
+            pgemm_limbs = (pgemm_limbs_req == 6 || pgemm_limbs_req == 9) ? pgemm_limbs_req : 0;
+        }
+        if (limbs_kmin_req >= 0)
+        {
+            limbs_kmin = std::max(57, limbs_kmin_req); // (at least four chunks of 16: k8 >= 57 rounds to 64)
         }
         if (pipeline)
         {
@@ -574,7 +601,16 @@ struct Ekf : EkfBase
     }
 
     // k8 columns go through ekf_downdate_psym4_f32 (see launch_downdate)
-    bool psym4_takes(int k8) const { return sizeof(T) == 4 && k8 <= 128 && lower && tune_downdate == 0 && ldp < 32768; }
+    bool psym4_takes(int k8) const
+    {
+        return sizeof(T) == 4 && (k8 <= 128 || limbs_take(k8)) && lower && tune_downdate == 0 && ldp < 32768;
+    }
+    // ... or through ekf_downdate_psym5_bf16 (which pads its own limb store)
+    bool limbs_take(int k8) const
+    {
+        return sizeof(T) == 4 && pgemm_limbs > 0 && k8 >= limbs_kmin && k8 <= 256 && lower && tune_downdate == 0 &&
+               ldp < 32768;
+    }
 
     int launch_negcol_fix(T* W, int kcols, hipStream_t st)
     {
@@ -703,7 +739,7 @@ struct Ekf : EkfBase
         }
         if (P)
         {
-            if (lower && n > kTile)
+            if (lower)
             {
                 const int g = (n + 31) / 32;
                 hipLaunchKernelGGL(ekf_mirror_upper_kernel<T>, dim3(g, g), dim3(256), 0, stream, dP, ldp, n);
@@ -1832,7 +1868,123 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
         {
             G = std::min(G, pgemm_wgs);
         }
-        if (k8 <= 128 && lower && tune_downdate == 0 && ldp < 32768)
+        if (limbs_take(k8))
+        {
+            // f32 products as exact bf16 limb products on the bf16 matrix cores (ekf_pgemm_limbs.hpp)
+            const int    nch  = k8 <= 64 ? 4 : (k8 <= 96 ? 6 : (k8 <= 128 ? 8 : (k8 <= 192 ? 12 : 16)));
+            const int    kgs  = 2 * nch;
+            const int    rows = round_up(n, kTile);
+            const size_t need = (size_t)2 * 3 * kgs * rows * 16;
+            if (need > wb_bytes)
+            {
+                CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // (grows with n and the window: rare)
+                (void)hipFree(dWb);
+                dWb      = nullptr;
+                wb_bytes = 0;
+                const size_t cap = (size_t)2 * 3 * 32 * round_up(ncap, kTile) * 16; // every window up to 256 columns
+                CSLAM_HIP_TRY(hipMalloc(&dWb, cap));
+                wb_bytes = cap;
+            }
+            if (tilesM_built != tiles)
+            {
+                // Morton order over the lower triangle, eight equal segments
+                auto spread = [](unsigned v) {
+                    v &= 0xFFFF;
+                    v = (v | (v << 8)) & 0x00FF00FF;
+                    v = (v | (v << 4)) & 0x0F0F0F0F;
+                    v = (v | (v << 2)) & 0x33333333;
+                    v = (v | (v << 1)) & 0x55555555;
+                    return v;
+                };
+                std::vector<std::pair<unsigned, int2>> keyed;
+                keyed.reserve((size_t)tiles * (tiles + 1) / 2);
+                for (int tj = 0; tj < tiles; tj++)
+                {
+                    for (int ti = tj; ti < tiles; ti++)
+                    {
+                        keyed.push_back({spread((unsigned)ti) | (spread((unsigned)tj) << 1), make_int2(ti, tj)});
+                    }
+                }
+                std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+                std::vector<int2> hl(keyed.size());
+                for (size_t i = 0; i < keyed.size(); i++)
+                {
+                    hl[i] = keyed[i].second;
+                }
+                int off[9];
+                for (int sgi = 0; sgi <= 8; sgi++)
+                {
+                    off[sgi] = (int)((size_t)hl.size() * sgi / 8);
+                }
+                CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+                (void)hipFree(dTilesM);
+                dTilesM = nullptr;
+                CSLAM_HIP_TRY(hipMalloc(&dTilesM, hl.size() * sizeof(int2)));
+                CSLAM_HIP_TRY(hipMemcpy(dTilesM, hl.data(), hl.size() * sizeof(int2), hipMemcpyHostToDevice));
+                if (dSegOff == nullptr)
+                {
+                    CSLAM_HIP_TRY(hipMalloc(&dSegOff, 9 * sizeof(int)));
+                    CSLAM_HIP_TRY(hipMalloc(&dTicketX, 16 * sizeof(int)));
+                    CSLAM_HIP_TRY(hipMemset(dTicketX, 0, 16 * sizeof(int)));
+                }
+                CSLAM_HIP_TRY(hipMemcpy(dSegOff, off, sizeof(off), hipMemcpyHostToDevice));
+                tilesM_built = tiles;
+            }
+            hipLaunchKernelGGL(ekf_limb_split_kernel, dim3((rows + 255) / 256, kgs), dim3(256), 0, stream, W, ldp, k, rows, kgs,
+                               dWb);
+            // ring of 3 panel buffers (72 KB: two workgroups per compute unit) or 6 (144 KB: one), env CSLAM_LIMBS_RING
+            static const int ring_env = getenv("CSLAM_LIMBS_RING") ? atoi(getenv("CSLAM_LIMBS_RING")) : 3;
+            const int        ring     = (ring_env == 6 && nch >= 6) ? 6 : 3;
+            if (pgemm_wgs <= 0 && !pipeline)
+            {
+                G = std::min(n_sym_tiles, (ring == 6 ? 1 : 2) * num_cus);
+            }
+            limb_parity ^= 1;
+            const bool nt = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
+#define CSLAM_LAUNCH_PSYM5(MODE, NCH, NP, RR)                                                                          \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set)                                                                                                 \
+        {                                                                                                              \
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_downdate_psym5_bf16<MODE, NCH, NP, RR>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));               \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((ekf_downdate_psym5_bf16<MODE, NCH, NP, RR>), dim3(G), block, (size_t)RR * 24576, stream, dP, ldp, \
+                           (const uint4*)dWb, rows, (const int2*)dTilesM, (const int*)dSegOff, dTicketX + 8 * limb_parity,  \
+                           dTicketX + 8 * (limb_parity ^ 1));                                                          \
+    } while (0)
+#define CSLAM_LAUNCH_PSYM5R(NCH, RR)                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (pgemm_limbs == 6)                                                                                          \
+        {                                                                                                              \
+            if (nt) { CSLAM_LAUNCH_PSYM5(1, NCH, 6, RR); } else { CSLAM_LAUNCH_PSYM5(0, NCH, 6, RR); }                 \
+        }                                                                                                              \
+        else                                                                                                           \
+        {                                                                                                              \
+            if (nt) { CSLAM_LAUNCH_PSYM5(1, NCH, 9, RR); } else { CSLAM_LAUNCH_PSYM5(0, NCH, 9, RR); }                 \
+        }                                                                                                              \
+    } while (0)
+#define CSLAM_LAUNCH_PSYM5N(NCH)                                                                                       \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (ring == 6) { CSLAM_LAUNCH_PSYM5R(NCH, 6); } else { CSLAM_LAUNCH_PSYM5R(NCH, 3); }                          \
+    } while (0)
+            switch (nch)
+            {
+            case 4: CSLAM_LAUNCH_PSYM5R(4, 3); break;
+            case 6: CSLAM_LAUNCH_PSYM5N(6); break;
+            case 8: CSLAM_LAUNCH_PSYM5N(8); break;
+            case 12: CSLAM_LAUNCH_PSYM5N(12); break;
+            default: CSLAM_LAUNCH_PSYM5N(16); break;
+            }
+#undef CSLAM_LAUNCH_PSYM5N
+#undef CSLAM_LAUNCH_PSYM5R
+#undef CSLAM_LAUNCH_PSYM5
+        }
+        else if (k8 <= 128 && lower && tune_downdate == 0 && ldp < 32768)
         {
             // every memory operation interleaved with the MFMA loop; two (k <= 64) or four (k <= 128) chunks of 32
             launch_parity++;
@@ -2213,6 +2365,14 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* pv = getenv("CSLAM_PIPELINE"))
     {
         b->pipeline = atoi(pv) ? 1 : 0;
+    }
+    if (const char* lv = getenv("CSLAM_PGEMM_LIMBS"))
+    {
+        b->pgemm_limbs_req = atoi(lv);
+    }
+    if (const char* lk = getenv("CSLAM_LIMBS_KMIN"))
+    {
+        b->limbs_kmin_req = atoi(lk);
     }
     if (const char* gw = getenv("CSLAM_GATHER_WIDE"))
     {

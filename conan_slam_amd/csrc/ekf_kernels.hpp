@@ -49,11 +49,16 @@ struct Vec4<float>
 };
 
 // Block-lower storage (cslam_ekf.hip "lower" mode): P is symmetric and only 128x128 tiles on or below the
-// tile diagonal are maintained; element (i,j) with tile(i) < tile(j) is read from its mirror (j,i).
+// tile diagonal are maintained; element (i,j) with tile(i) < tile(j) is read from its mirror (j,i).  Inside a
+// DIAGONAL tile both halves are stored and updated, and the element-wise lower triangle is the authoritative one:
+// every reader takes (max(i,j), min(i,j)) there.  (The f32-MFMA and f64 P-GEMMs produce the two halves bit-identical
+// anyway; the bf16-limb P-GEMM adds the limb products of (i,j) and (j,i) in different orders, so its halves differ in
+// the last bit -- reading one of them keeps P exactly symmetric for every consumer.)
 template <typename T>
 __device__ inline T p_sym(const T* __restrict__ P, int ldp, int i, int j, int lower)
 {
-    const bool direct = !lower || ((i >> 7) >= (j >> 7));
+    const int  ti = i >> 7, tj = j >> 7;
+    const bool direct = !lower || (ti > tj) || (ti == tj && i >= j);
     return direct ? P[(size_t)j * ldp + i] : P[(size_t)i * ldp + j];
 }
 

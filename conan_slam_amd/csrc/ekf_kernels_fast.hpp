@@ -3395,7 +3395,7 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
         if (have_next && tid == 0)
         {
             const int zero = 0, one = 1;
-            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_raw) : "v"(zero), "v"(one), "s"(ticket) : "memory");
+            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_raw) : "v"(zero), "v"(one), "s"(ticket) : "memory");
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -3688,7 +3688,7 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
                         }
                     }
                     const int zero = 0, one = 1;
-                    asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_new) : "v"(zero), "v"(one), "s"(ticket) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_new) : "v"(zero), "v"(one), "s"(ticket) : "memory");
                 }
                 acc0 = acc1 = acc2 = acc3 = f32x16{0};
             }
@@ -3830,7 +3830,7 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // Block-lower storage -> full symmetric matrix (used by get_state): every tile above the tile diagonal is
-// filled with the transpose of its mirror.  32x32 sub-tiles through LDS so both sides are coalesced.
+// filled with the transpose of its mirror, and so is the element-wise upper triangle of every diagonal tile.  32x32 sub-tiles through LDS so both sides are coalesced.
 // grid = (ceil(n/32), ceil(n/32)); blocks not strictly above the 128-tile diagonal exit.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -3839,7 +3839,9 @@ __global__ void __launch_bounds__(256) ekf_mirror_upper_kernel(T* __restrict__ P
     __shared__ T tile[32][33];
     const int    bi = blockIdx.x * 32; // destination rows (upper part: small row index)
     const int    bj = blockIdx.y * 32; // destination columns
-    if ((bi >> 7) >= (bj >> 7))
+    // tiles above the tile diagonal, and inside a diagonal tile the element-wise upper triangle (see p_sym)
+    const bool diag_tile = (bi >> 7) == (bj >> 7);
+    if ((bi >> 7) > (bj >> 7) || (diag_tile && bi > bj))
     {
         return;
     }
@@ -3855,7 +3857,7 @@ __global__ void __launch_bounds__(256) ekf_mirror_upper_kernel(T* __restrict__ P
     {
         // destination element (bi + tx, bj + c) = source (bj + c, bi + tx) = tile[tx][c]
         const int di = bi + tx, dj = bj + c;
-        if (di < n && dj < n)
+        if (di < n && dj < n && (bi != bj || di < dj))
         {
             P[(size_t)dj * ldp + di] = tile[tx][c];
         }

@@ -730,3 +730,77 @@ def test_device_resident_bad_feature_index_is_flagged_not_faulted(gpu_required):
     Xg, Pg = eng.get_state()
     assert np.all(np.isfinite(Xg)) and np.all(np.isfinite(Pg))
     eng.close()
+
+
+@pytest.mark.parametrize("limbs", [9, 6, 0])
+def test_pgemm_against_an_f64_product_of_the_same_panel(gpu_required, monkeypatch, limbs):
+    """One covariance downdate P -= W1*W1^T (slam.h:260) at N = 3000 (1 128 tiles, several per workgroup) checked
+    element by element against the f64 product of the SAME f32 panel (cslam_ekf_debug_last_update): the f32-MFMA kernel
+    (limbs = 0) and the bf16-limb kernel (ekf_pgemm_limbs.hpp; 9 limb pairs = every product exact, 6 = without the three
+    pairs below 2^-24 of a product) must all sit inside the rounding bound of an f32 dot product of length k --
+    half an ulp of the result plus a few 1e-7 of sum |w_ik w_jk| -- and return an exactly symmetric P."""
+    from conan_slam_amd import EKF
+    from conan_slam_amd.synth import Workload
+
+    N = 3000
+    monkeypatch.setenv("CSLAM_PGEMM_LIMBS", str(limbs))
+    monkeypatch.setenv("CSLAM_LIMBS_KMIN", "57")  # the k = 64 launch of an immediate update goes through the limb kernel too
+    w = Workload(N, 32, np.float32)
+    (v, swa), (Z, idf) = w.controls(0), w.observations(0)
+    e = EKF(N, dtype=np.float32, quirks=TEXTBOOK)
+    e.set_state(w.X0, w.P0)
+    e.predict(v, swa, w.QE, w.wb, w.dt)  # (touches the pose stripe only: the map block is still P0's)
+    e.update(Z, w.RE, idf, batch=True)
+    W1 = e.debug_last_update()["W1"].astype(np.float64)[3:, :]
+    _, P = e.get_state()
+    assert e.factor_status() == 0
+    e.close()
+    M = P.copy()
+    M[:3, :3] = 0
+    assert np.array_equal(M, M.T)
+    expected = w.P0[3:, 3:].astype(np.float64) - W1 @ W1.T
+    # (the subtraction rounds at the size of its operands, not of the possibly much smaller difference)
+    # (the dot-product term: the worst of 36 million elements, k = 64 roundings each; with 3e-7 in its place the worst
+    # error / bound was 2.1 for the f32-MFMA kernel and 1.6 for the limb kernels, nine pairs or six: exact products
+    # and the matrix core's wider sums make the limb form the more accurate of the two)
+    bound = 1.0e-7 * np.abs(w.P0[3:, 3:].astype(np.float64)) + 2.0e-6 * (np.abs(W1) @ np.abs(W1).T) + 1e-30
+    err = np.abs(P[3:, 3:].astype(np.float64) - expected)
+    worst = float((err / bound).max())
+    assert worst <= 1.0, f"limbs={limbs}: error / bound = {worst}"
+
+
+@pytest.mark.parametrize("limbs", [9, 6])
+@pytest.mark.parametrize("defer", [128, 256])
+def test_limb_pgemm_matches_the_f32_mfma_pgemm(gpu_required, monkeypatch, limbs, defer):
+    """The f32 P-GEMM on the bf16 matrix cores against the f32-MFMA P-GEMM through whole deferral windows (N = 3000,
+    k = 128 and k = 256 flushes): both are f32 sums of the same products in different orders, so the two filters agree
+    as closely as the immediate and the deferred engine do (test_full_size_immediate_and_deferred_pgemm_agree)."""
+    from conan_slam_amd import EKF
+    from conan_slam_amd.synth import Workload
+
+    N = 3000
+    w = Workload(N, 32, np.float32)
+    steps = [(w.controls(t), w.observations(t)) for t in range(defer // 64 + 2)]
+
+    def run(env_limbs):
+        monkeypatch.setenv("CSLAM_PGEMM_LIMBS", str(env_limbs))
+        e = EKF(N, dtype=np.float32, quirks=TEXTBOOK)
+        e.set_state(w.X0, w.P0)
+        e.set_deferred(defer)
+        for (v, swa), (Z, idf) in steps:
+            e.predict(v, swa, w.QE, w.wb, w.dt)
+            e.update(Z, w.RE, idf, batch=True)
+        X, P = e.get_state()
+        assert e.factor_status() == 0
+        e.close()
+        return X, P
+
+    X0, P0 = run(0)
+    X1, P1 = run(limbs)
+    M = P1.copy()
+    M[:3, :3] = 0
+    assert np.array_equal(M, M.T)
+    assert_close("X", X1, X0, 1e-5)
+    assert_close("P", P1, P0, 3e-5)
+    assert abs(float(np.trace(P1.astype(np.float64))) - float(np.trace(P0.astype(np.float64)))) <= 2e-6 * float(
+        np.trace(P0.astype(np.float64)))
