@@ -3,7 +3,7 @@
 # Outputs land in gpurun_out/prof_r02/; tools/pmc_summary.py condenses the counter CSVs.
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r02
+O=$R/gpurun_out/prof_r02c
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -36,3 +36,10 @@ python3 bench.py --obs 64 --defer 0 --no-cpu-baseline --no-extras --stage-profil
 CSLAM_PIPELINE=1 python3 bench.py --no-cpu-baseline --no-extras > $O/bench_pipelined.json 2>> $O/bench.err || true
 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2>> $O/bench.err || true
 tail -c 400 $O/bench_ekf.json
+echo
+CSLAM_PGEMM_LIMBS=9 python3 bench.py --no-cpu-baseline --no-extras > $O/bench_limbs9_d128.json 2>> $O/bench.err || true
+CSLAM_PGEMM_LIMBS=6 python3 bench.py --no-cpu-baseline --no-extras > $O/bench_limbs6_d128.json 2>> $O/bench.err || true
+CSLAM_PGEMM_LIMBS=6 python3 bench.py --no-cpu-baseline --no-extras --defer 256 > $O/bench_limbs6_d256.json 2>> $O/bench.err || true
+CSLAM_PGEMM_LIMBS=9 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_limbs9 -o run -- python3 $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-extras > $O/stats_limbs9.log 2>&1 || true
+for f in bench_ekf bench_f64_n1000 bench_pf bench_mc bench_sequential bench_m64 bench_driver_shape bench_limbs9_d128 bench_limbs6_d128 bench_limbs6_d256; do python3 -c "
+import json;d=json.loads(open('$O/$f.json').read().strip().split('\n')[-1]);print('$f', round(d['value']), round(d['ms_per_step'],5), (d.get('roofline') or {}).get('frac'))" || true; done
