@@ -244,6 +244,15 @@ def pgemm_model(n, k_launch, dname, storage):
         depth = 64 if k8 <= 64 else (96 if k8 <= 96 else (128 if k8 <= 128 else (k8 + 63) // 64 * 64))  # chunks x chunk depth
         name = ("ekf_downdate_psym4_f32<0,2,32>" if k8 <= 64 else ("ekf_downdate_psym4_f32<0,4,24>" if k8 <= 96 else
                 "ekf_downdate_psym4_f32<0,4,32>")) if k8 <= 128 else "ekf_downdate_psym_f32<64,true,false>"
+        limbs = int(os.environ.get("CSLAM_PGEMM_LIMBS", "0") or 0)
+        kmin = max(57, int(os.environ.get("CSLAM_LIMBS_KMIN", "65") or 65))
+        if dname == "f32" and limbs in (6, 9) and kmin <= k8 <= 256:
+            # the optional bf16-limb P-GEMM (ekf_pgemm_limbs.hpp): chunks of 16 columns, `limbs` bf16 MFMA products per
+            # f32 product; priced against the dense bf16 matrix-core peak
+            nch = 4 if k8 <= 64 else (6 if k8 <= 96 else (8 if k8 <= 128 else (12 if k8 <= 192 else 16)))
+            return {"kernel": f"ekf_downdate_psym5_bf16<.,{nch},{limbs},3>", "bytes": nt * 65536.0 * 2 + 1.0 * n * k8 * s,
+                    "flops_issued": nt * 128.0 * 128.0 * (16 * nch) * 2 * limbs, "full_storage_bytes": full_bytes,
+                    "n_sym_tiles": nt, "mfma_peak_tf": 2500.0}
         return {"kernel": name, "bytes": nt * 65536.0 * 2 + 1.0 * n * k8 * s, "flops_issued": nt * 128.0 * 128.0 * depth * 2,
                 "full_storage_bytes": full_bytes, "n_sym_tiles": nt}
     tiles = ((n + 127) // 128) ** 2
@@ -268,13 +277,14 @@ def roofline_record(n, k_launch, dname, storage, launch_s, launches, landmarks, 
     tf = md["flops_issued"] / launch_s / 1e12 if launch_s and launch_s > 0 else None
     # which roof bounds the launch: time to move its bytes at the HBM peak vs time to issue its flops at the MFMA peak
     t_hbm = md["bytes"] / (HBM_PEAK_GBS * 1e9)
-    t_mfma = md["flops_issued"] / (MFMA_PEAK_TF[dname] * 1e12)
+    mfma_peak = md.get("mfma_peak_tf", MFMA_PEAK_TF[dname])
+    t_mfma = md["flops_issued"] / (mfma_peak * 1e12)
     mfma_bound = t_mfma > t_hbm
     rec = {
         "kernel": md["kernel"], "bound": "mfma" if mfma_bound else "hbm",
-        "achieved": tf if mfma_bound else ach, "peak": MFMA_PEAK_TF[dname] if mfma_bound else HBM_PEAK_GBS,
+        "achieved": tf if mfma_bound else ach, "peak": mfma_peak if mfma_bound else HBM_PEAK_GBS,
         "unit": "TFLOP/s" if mfma_bound else "GB/s",
-        "frac": ((tf / MFMA_PEAK_TF[dname]) if tf else None) if mfma_bound else ((ach / HBM_PEAK_GBS) if ach else None),
+        "frac": ((tf / mfma_peak) if tf else None) if mfma_bound else ((ach / HBM_PEAK_GBS) if ach else None),
         "hbm_gbs": ach, "hbm_frac": (ach / HBM_PEAK_GBS) if ach else None,
         "roof_times_us": {"hbm": t_hbm * 1e6, "mfma": t_mfma * 1e6},
         "traffic": traffic,
@@ -284,7 +294,7 @@ def roofline_record(n, k_launch, dname, storage, launch_s, launches, landmarks, 
                         if storage == "lower" else "full storage: 2 n^2 s + n k s (SURVEY 8d)"),
         "n_sym_tiles": md["n_sym_tiles"],
         "launch_us": launch_s * 1e6 if launch_s else None, "launches_timed": launches, "k_per_launch": k_launch,
-        "mfma_tflops_issued": tf, "mfma_frac_of_peak": (tf / MFMA_PEAK_TF[dname]) if tf else None,
+        "mfma_tflops_issued": tf, "mfma_frac_of_peak": (tf / mfma_peak) if tf else None,
         "mfma_flops_model": "issued: tiles x 128^2 x (32-column chunks x 32) x 2 (a symmetric kernel issues ~n^2 k, not 2 n^2 k)",
         # SURVEY 8d's full-storage formula for the same launch: what a non-symmetric implementation would have to
         # move; NOT a fraction of anything this kernel does
