@@ -174,6 +174,7 @@ struct Pf : PfBase
         (void)hipFree(dSumsG);
         (void)hipFree(dWall);
         (void)hipFree(dSelG);
+        (void)hipFree(dCumG);
         (void)hipFree(dKeepG);
         (void)hipFree(dSendIdx);
         (void)hipFree(dCounts);
@@ -709,10 +710,6 @@ struct Pf : PfBase
         {
             return fail(CSLAM_ERR_BAD_ARG, "pf_resample_local: null select");
         }
-        if (np > kPfPlanMax)
-        {
-            return fail(CSLAM_ERR_CAPACITY, "pf_resample_local: %d particles (limit %d): use the sharded path", np, kPfPlanMax);
-        }
         int rc = use_device();
         if (rc)
         {
@@ -767,6 +764,7 @@ struct Pf : PfBase
     double* dSumsG   = nullptr;
     T*      dWall    = nullptr;
     T*      dSelG    = nullptr;
+    T*      dCumG    = nullptr; // running sum of the gathered weights (pf_keep_kernel)
     int*    dKeepG   = nullptr;
     int*    dSendIdx = nullptr;
     int*    dCounts  = nullptr;
@@ -787,10 +785,6 @@ struct Pf : PfBase
             return fail(CSLAM_ERR_BAD_ARG, "pf_resample_sharded: null communicator or select");
         }
         const int world = c->world, rank = c->rank, L = np, N = np * world;
-        if (N > kPfPlanMax)
-        {
-            return fail(CSLAM_ERR_CAPACITY, "pf_resample_sharded: %d particles in total (limit %d)", N, kPfPlanMax);
-        }
         int rc = use_device();
         if (rc)
         {
@@ -803,6 +797,7 @@ struct Pf : PfBase
             (void)hipFree(dSumsG);
             (void)hipFree(dWall);
             (void)hipFree(dSelG);
+            (void)hipFree(dCumG);
             (void)hipFree(dKeepG);
             (void)hipFree(dSendIdx);
             (void)hipFree(dCounts);
@@ -813,6 +808,7 @@ struct Pf : PfBase
             CSLAM_HIP_TRY(hipMalloc(&dSumsG, 2 * sizeof(double)));
             CSLAM_HIP_TRY(hipMalloc(&dWall, (size_t)N * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dSelG, (size_t)N * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&dCumG, (size_t)N * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dKeepG, (size_t)N * sizeof(int)));
             CSLAM_HIP_TRY(hipMalloc(&dSendIdx, (size_t)N * sizeof(int)));
             CSLAM_HIP_TRY(hipMalloc(&dCounts, (size_t)2 * world * sizeof(int)));
@@ -859,7 +855,7 @@ struct Pf : PfBase
         {
             return rc;
         }
-        hipLaunchKernelGGL(pf_keep_kernel<T>, dim3(1), dim3(256), 0, stream, dWall, N, dSelG, dKeepG);
+        hipLaunchKernelGGL(pf_keep_kernel<T>, dim3(1), dim3(256), 0, stream, dWall, N, dSelG, dKeepG, dCumG);
         CSLAM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(pf_exchange_plan_kernel<0>, dim3(1), dim3(256), 0, stream, dKeepG, N, L, rank, world, dSendIdx,
                            dCounts);
@@ -972,10 +968,6 @@ struct Pf : PfBase
         if (!Qv || !Rv || m < 0 || (m > 0 && (!Z || !idf || !normals)) || !select)
         {
             return fail(CSLAM_ERR_BAD_ARG, "pf_observation_step: bad arguments");
-        }
-        if (np > kPfPlanMax)
-        {
-            return fail(CSLAM_ERR_CAPACITY, "pf_observation_step: %d particles (limit %d)", np, kPfPlanMax);
         }
         int rc = use_device();
         if (rc || (rc = check_idf(idf, m, "pf_observation_step")) || (rc = ensure_m(std::max(m, 1))) ||

@@ -893,9 +893,91 @@ __global__ void __launch_bounds__(256) pf_scale_weights_kernel(T* __restrict__ w
 // same sequence of roundings as the reference's loop), and keep[c] = first i with cum[i] > select[c] (equal to the
 // reference's two-pointer walk because select is increasing).  info[0] = Neff, info[1] = 1 if resampling happens.
 // The kernels that move the particles afterwards take `enable` and return at once when it is 0.
-// One workgroup; np <= kPfPlanMax (the sequential running sum bounds it).
+// One workgroup (the running sum is sequential); any np: beyond kPfPlanMax the weights go through LDS in stages.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPfPlanMax = 8192;
+constexpr int kPfPlanMax = 8192; // particles staged in LDS at once (more: the running sum goes on chunk by chunk)
+
+// PF.cpp:559-563: cum[i] = w[0] + ... + w[i], summed sequentially in the particle dtype by ONE lane (the reference's
+// sequence of roundings), staged through LDS kPfPlanMax weights at a time (one lane walking global memory took 65 us for
+// 512 particles: a dependent L2 round trip per element).  The sums go to cum[] (global); for np <= kPfPlanMax they are
+// also still in s_cum afterwards.  Called by every thread of the one workgroup.
+template <typename T>
+__device__ __forceinline__ void pf_running_sum(const T* __restrict__ w, int np, T* __restrict__ cum,
+                                               __attribute__((address_space(3))) T* s_cum)
+{
+    // (s_cum is typed as an LDS pointer so that the chain below uses ds_read / ds_write whatever the inliner does)
+    T run = (T)0; // (lives in thread 0)
+    for (int base = 0; base < np; base += kPfPlanMax)
+    {
+        const int len = min(kPfPlanMax, np - base);
+        if (base > 0)
+        {
+            __syncthreads(); // the previous chunk has been copied out
+        }
+        for (int i = threadIdx.x; i < len; i += 256)
+        {
+            s_cum[i] = w[base + i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            int i = 0;
+            if (base == 0)
+            {
+                run = s_cum[0];
+                i   = 1;
+            }
+            // eight weights are read ahead of the eight dependent additions: left to the compiler this form of the loop
+            // ran one LDS round trip per element (the plan kernel took 25 us for 512 particles instead of 11.6)
+            for (; i + 8 <= len; i += 8)
+            {
+                T v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                {
+                    v[u] = s_cum[i + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                {
+                    run          = run + v[u];
+                    s_cum[i + u] = run;
+                }
+            }
+            for (; i < len; i++)
+            {
+                run      = run + s_cum[i];
+                s_cum[i] = run;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += 256)
+        {
+            cum[base + i] = s_cum[i];
+        }
+    }
+    __syncthreads();
+}
+
+// first i in [0, np) with cum[i] > sc, else 0 (PF.cpp:565-574: the reference leaves keep[c] = 0 then)
+template <typename T>
+__device__ __forceinline__ int pf_first_above(const __attribute__((address_space(3))) T* cumv, int np, T sc)
+{
+    int lo = 0, hi = np;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (sc < cumv[mid])
+        {
+            hi = mid;
+        }
+        else
+        {
+            lo = mid + 1;
+        }
+    }
+    return (lo < np) ? lo : 0;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w, int np, const T* __restrict__ select,
@@ -947,46 +1029,38 @@ __global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w
     {
         return;
     }
-    // PF.cpp:559-563: cumulative sum, sequential, in the particle dtype.  The weights are staged in LDS first and the
-    // running sum stays there (one lane walking global memory took 65 us for 512 particles: a dependent L2 round trip
-    // per element).
     __shared__ T s_cum[kPfPlanMax];
-    for (int i = threadIdx.x; i < np; i += 256)
+    pf_running_sum<T>(w, np, cum, (__attribute__((address_space(3))) T*)s_cum);
+    if (np <= kPfPlanMax) // (workgroup-uniform) the search reads LDS
     {
-        s_cum[i] = w[i];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        T run = s_cum[0];
-        for (int i = 1; i < np; i++)
+        for (int c = threadIdx.x; c < np; c += 256)
         {
-            run      = run + s_cum[i];
-            s_cum[i] = run;
+            keep[c] = pf_first_above<T>((const __attribute__((address_space(3))) T*)s_cum, np, select[c]);
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < np; i += 256)
+    else // beyond one LDS stage: the sums this workgroup has just written to global memory
     {
-        cum[i] = s_cum[i]; // (kept in global memory for inspection; the search below reads LDS)
-    }
-    for (int c = threadIdx.x; c < np; c += 256) // PF.cpp:565-574
-    {
-        const T sc = select[c];
-        int     lo = 0, hi = np; // first i in [0, np) with cum[i] > sc; none -> the reference leaves keep[c] = 0
-        while (lo < hi)
+        __threadfence();
+        __syncthreads();
+        const volatile T* cv = cum;
+        for (int c = threadIdx.x; c < np; c += 256)
         {
-            const int mid = (lo + hi) >> 1;
-            if (sc < s_cum[mid])
+            const T sc = select[c];
+            int     lo = 0, hi = np;
+            while (lo < hi)
             {
-                hi = mid;
+                const int mid = (lo + hi) >> 1;
+                if (sc < cv[mid])
+                {
+                    hi = mid;
+                }
+                else
+                {
+                    lo = mid + 1;
+                }
             }
-            else
-            {
-                lo = mid + 1;
-            }
+            keep[c] = (lo < np) ? lo : 0;
         }
-        keep[c] = (lo < np) ? lo : 0;
     }
 }
 
@@ -995,41 +1069,40 @@ __global__ void __launch_bounds__(256) pf_resample_plan_kernel(T* __restrict__ w
 // sum (one lane, particle dtype, index order) and the same search as pf_resample_plan_kernel.  One workgroup.
 template <typename T>
 __global__ void __launch_bounds__(256) pf_keep_kernel(const T* __restrict__ w, int np, const T* __restrict__ select,
-                                                       int* __restrict__ keep)
+                                                       int* __restrict__ keep, T* __restrict__ cum)
 {
     __shared__ T s_cum[kPfPlanMax];
-    for (int i = threadIdx.x; i < np; i += 256)
+    pf_running_sum<T>(w, np, cum, (__attribute__((address_space(3))) T*)s_cum);
+    if (np <= kPfPlanMax)
     {
-        s_cum[i] = w[i];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        T run = s_cum[0];
-        for (int i = 1; i < np; i++)
+        for (int c = threadIdx.x; c < np; c += 256)
         {
-            run      = run + s_cum[i];
-            s_cum[i] = run;
+            keep[c] = pf_first_above<T>((const __attribute__((address_space(3))) T*)s_cum, np, select[c]);
         }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < np; c += 256)
+    else
     {
-        const T sc = select[c];
-        int     lo = 0, hi = np;
-        while (lo < hi)
+        __threadfence();
+        __syncthreads();
+        const volatile T* cv = cum;
+        for (int c = threadIdx.x; c < np; c += 256)
         {
-            const int mid = (lo + hi) >> 1;
-            if (sc < s_cum[mid])
+            const T sc = select[c];
+            int     lo = 0, hi = np;
+            while (lo < hi)
             {
-                hi = mid;
+                const int mid = (lo + hi) >> 1;
+                if (sc < cv[mid])
+                {
+                    hi = mid;
+                }
+                else
+                {
+                    lo = mid + 1;
+                }
             }
-            else
-            {
-                lo = mid + 1;
-            }
+            keep[c] = (lo < np) ? lo : 0;
         }
-        keep[c] = (lo < np) ? lo : 0;
     }
 }
 
@@ -1041,7 +1114,7 @@ __global__ void __launch_bounds__(256) pf_keep_kernel(const T* __restrict__ w, i
 //                 rank, ascending g (hence grouped by destination rank)
 //   counts[d]             records this rank sends to rank d      (d = 0..world-1, including itself)
 //   counts[world + s]     records this rank receives from rank s (they fill its slots in order)
-// One workgroup; N = L*world <= kPfPlanMax.
+// One workgroup.
 template <int DUMMY = 0>
 __global__ void __launch_bounds__(256) pf_exchange_plan_kernel(const int* __restrict__ keep, int N, int L, int rank, int world,
                                                                 int* __restrict__ send_idx, int* __restrict__ counts)

@@ -384,7 +384,7 @@ def resample_particles(shard, comm, n_effective: int, resample_status: bool, sel
     `uniforms` (N uniform[0,1) draws that every rank must pass identically).  Returns (neff, resampled)."""
     n_local = shard.n_local
     n = n_local * comm.world
-    if comm.world == 1 and hasattr(shard, "resample_local") and n_local <= 8192 and not getattr(shard, "host_resample", False):
+    if comm.world == 1 and hasattr(shard, "resample_local") and not getattr(shard, "host_resample", False):
         # one shard holds everything: sums, normalisation, Neff, decision, keep[] and the moves stay on the device
         if select is None:
             assert uniforms is not None, "pass select[] or the uniform draws it is built from"

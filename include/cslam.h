@@ -235,7 +235,8 @@ int cslam_pf_unpack(cslam_pf_t h, const int* dst_idx, int count, const void* d_r
  * particle set: weight sums, normalisation, Neff, the decision (Neff < n_effective && resample_status), keep[] and
  * the particle moves all run on the device; `select` are the N strata positions (PF.cpp:557, host pointer).
  * neff / resampled may be NULL (then nothing returns to the host). Same results as weight_sums + scale_weights +
- * host keep[] + gather_local. Limited to 8192 particles (the running sum is sequential, as in the reference). */
+ * host keep[] + gather_local.  Any particle count (the running sum is sequential, as in the reference: 8192 weights
+ * are staged in LDS at a time). */
 int cslam_pf_resample_local(cslam_pf_t h, const void* select, double n_effective, int resample_status, double* neff,
                             int* resampled);
 int cslam_pf_gather_local(cslam_pf_t h, const int* keep, double w_new);

@@ -232,12 +232,14 @@ def test_pack_unpack_roundtrip(gpu_required):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_device_resample_equals_the_host_planned_one(gpu_required, dtype):
+@pytest.mark.parametrize("npart", [512, 20000])
+def test_device_resample_equals_the_host_planned_one(gpu_required, dtype, npart):
     """cslam_pf_resample_local (plan on the device) against weight_sums + scale + host keep[] + gather_local: the
-    same particles in the same slots, bit for bit, and the same Neff."""
+    same particles in the same slots, bit for bit, and the same Neff.  20 000 particles: more than one LDS stage of
+    the sequential running sum (kPfPlanMax = 8192 per stage)."""
     from conan_slam_amd.pf import SingleComm, resample_particles, stratified_random
 
-    npart, nf = 512, 5
+    nf = 5 if npart <= 1024 else 1
     parts = _random_particles(npart, nf, dtype, seed=31)
     rng = np.random.default_rng(32)
     w = rng.uniform(0.0, 1.0, npart) ** 5
@@ -250,7 +252,7 @@ def test_device_resample_equals_the_host_planned_one(gpu_required, dtype):
     ra = resample_particles(a, SingleComm(), int(0.75 * npart), True, select=select)
     rb = resample_particles(b, SingleComm(), int(0.75 * npart), True, select=select)
     assert ra[1] and rb[1] and abs(ra[0] - rb[0]) <= 1e-9 * abs(rb[0])
-    for i in range(0, npart, 37):
+    for i in range(0, npart, 37 if npart <= 1024 else 997):
         pa, pb = a.get_particle(i), b.get_particle(i)
         for x, y in zip(pa, pb):
             assert np.array_equal(np.asarray(x), np.asarray(y)), i
