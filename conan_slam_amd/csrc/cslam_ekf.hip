@@ -1932,13 +1932,8 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
             }
             hipLaunchKernelGGL(ekf_limb_split_kernel, dim3((rows + 255) / 256, kgs), dim3(256), 0, stream, W, ldp, k, rows, kgs,
                                dWb);
-            // ring of 3 panel buffers (72 KB: two workgroups per compute unit) or 6 (144 KB: one), env CSLAM_LIMBS_RING
-            static const int ring_env = getenv("CSLAM_LIMBS_RING") ? atoi(getenv("CSLAM_LIMBS_RING")) : 3;
-            const int        ring     = (ring_env == 6 && nch >= 6) ? 6 : 3;
-            if (pgemm_wgs <= 0 && !pipeline)
-            {
-                G = std::min(n_sym_tiles, (ring == 6 ? 1 : 2) * num_cus);
-            }
+            // (ring of 3 panel buffers, 72 KB: two workgroups per compute unit; a ring of 6 at one workgroup per unit
+            // was measured at 365 - 443 us and is not instantiated)
             limb_parity ^= 1;
             const bool nt = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
 #define CSLAM_LAUNCH_PSYM5(MODE, NCH, NP, RR)                                                                          \
@@ -1967,20 +1962,14 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
             if (nt) { CSLAM_LAUNCH_PSYM5(1, NCH, 9, RR); } else { CSLAM_LAUNCH_PSYM5(0, NCH, 9, RR); }                 \
         }                                                                                                              \
     } while (0)
-#define CSLAM_LAUNCH_PSYM5N(NCH)                                                                                       \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        if (ring == 6) { CSLAM_LAUNCH_PSYM5R(NCH, 6); } else { CSLAM_LAUNCH_PSYM5R(NCH, 3); }                          \
-    } while (0)
             switch (nch)
             {
             case 4: CSLAM_LAUNCH_PSYM5R(4, 3); break;
-            case 6: CSLAM_LAUNCH_PSYM5N(6); break;
-            case 8: CSLAM_LAUNCH_PSYM5N(8); break;
-            case 12: CSLAM_LAUNCH_PSYM5N(12); break;
-            default: CSLAM_LAUNCH_PSYM5N(16); break;
+            case 6: CSLAM_LAUNCH_PSYM5R(6, 3); break;
+            case 8: CSLAM_LAUNCH_PSYM5R(8, 3); break;
+            case 12: CSLAM_LAUNCH_PSYM5R(12, 3); break;
+            default: CSLAM_LAUNCH_PSYM5R(16, 3); break;
             }
-#undef CSLAM_LAUNCH_PSYM5N
 #undef CSLAM_LAUNCH_PSYM5R
 #undef CSLAM_LAUNCH_PSYM5
         }
