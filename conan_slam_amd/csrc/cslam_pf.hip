@@ -469,7 +469,7 @@ struct Pf : PfBase
             return rc;
         }
         const T* R = static_cast<const T*>(Rv);
-        hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(), m,
+        hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np * kPfSubLanes + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(), m,
                            R[0], R[1], R[2], R[3], dNormals());
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
@@ -1004,7 +1004,7 @@ struct Pf : PfBase
         CSLAM_HIP_TRY(hipGetLastError());
         if (m > 0)
         {
-            hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(),
+            hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np * kPfSubLanes + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(),
                                m, R[0], R[1], R[2], R[3], dNormals());
             CSLAM_HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), dObs,

@@ -605,13 +605,21 @@ __global__ void __launch_bounds__(64) pf_heading_kernel(PfStore<T> s, T phi, T R
 
 // ---------------------------------------------------------------- PF.cpp:502-544 (+ 343-359, 279-317, 62-68)
 // normals: [3][np] standard-normal draws (input)
+constexpr int kPfSubLanes = 8; // lanes per particle in pf_sample_proposal_kernel (= its observation chunk)
+
 template <typename T>
 __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, const T* __restrict__ Z,
                                                                  const int* __restrict__ idf, int m, T r00, T r10, T r01,
                                                                  T r11, const T* __restrict__ normals)
 {
-    int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= s.np)
+    // kPfSubLanes lanes per particle.  The sequential proposal updates (PF.cpp:502-530) are computed by all of them
+    // alike (same instructions on the same values: lanes are free, a wave of 64 particles used 8 waves of the whole
+    // chip); the m likelihood factors at the sampled pose (PF.cpp:343-359) are independent of one another, so sub-lane j
+    // evaluates observation j and the product is then formed in the reference's order from the shuffled factors.
+    const int gl  = blockIdx.x * 64 + threadIdx.x;
+    const int p   = gl / kPfSubLanes;
+    const int sub = threadIdx.x & (kPfSubLanes - 1);
+    if (p >= s.np) // (whole groups of sub-lanes leave together)
     {
         return;
     }
@@ -695,6 +703,7 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
     }
     // likelihood at the sampled pose (PF.cpp:343-359)
     T like = (T)1;
+    static_assert(kObsChunk == kPfSubLanes, "one observation of a chunk per sub-lane");
     for (int base = 0; base < m; base += kObsChunk)
     {
         if (m > kObsChunk) // (otherwise the chunk loaded above is still the right one)
@@ -705,26 +714,47 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
                 load_feature<T>(s, p, idf[min(base + j, m - 1)] - 1, xfc[j], pfc[j]);
             }
         }
+        // this sub-lane's observation of the chunk (selects, not a dynamically indexed register array)
+        T xf[2] = {xfc[0][0], xfc[0][1]}, pf[4] = {pfc[0][0], pfc[0][1], pfc[0][2], pfc[0][3]};
+#pragma unroll
+        for (int j = 1; j < kObsChunk; j++)
+        {
+            const bool mine = (j == sub);
+            xf[0]           = mine ? xfc[j][0] : xf[0];
+            xf[1]           = mine ? xfc[j][1] : xf[1];
+            pf[0]           = mine ? pfc[j][0] : pf[0];
+            pf[1]           = mine ? pfc[j][1] : pf[1];
+            pf[2]           = mine ? pfc[j][2] : pf[2];
+            pf[3]           = mine ? pfc[j][3] : pf[3];
+        }
+        const int i  = min(base + sub, m - 1); // (a sub-lane beyond m repeats the last one; its factor is not used)
+        T         lf;
+        {
+            T ZP[2], HV[6], HF[4], SF[4], V[2];
+            compute_jacobians<T>(XS, xf, pf, R, ZP, HV, HF, SF);
+            V[0] = Z[2 * i] - ZP[0];
+            V[1] = pi2pi<T>(Z[2 * i + 1] - ZP[1]);
+            lf   = gauss_evaluate<T, 2>(V, SF);
+        }
+        const int lane0 = (int)(threadIdx.x & ~(kPfSubLanes - 1));
 #pragma unroll
         for (int j = 0; j < kObsChunk; j++)
         {
-            const int i = base + j;
-            if (i >= m)
+            const T lj = __shfl(lf, lane0 + j);
+            if (base + j < m)
             {
-                continue;
+                like = like * lj; // the reference's order: ((1 * l0) * l1) * ...
             }
-        T xf[2] = {xfc[j][0], xfc[j][1]}, pf[4] = {pfc[j][0], pfc[j][1], pfc[j][2], pfc[j][3]};
-        T ZP[2], HV[6], HF[4], SF[4], V[2];
-        compute_jacobians<T>(XS, xf, pf, R, ZP, HV, HF, SF);
-        V[0] = Z[2 * i] - ZP[0];
-        V[1] = pi2pi<T>(Z[2 * i + 1] - ZP[1]);
-        like = like * gauss_evaluate<T, 2>(V, SF);
         }
     }
     T d1[3] = {X0[0] - XS[0], X0[1] - XS[1], pi2pi<T>(X0[2] - XS[2])};
     T d2[3] = {X[0] - XS[0], X[1] - XS[1], pi2pi<T>(X[2] - XS[2])};
     T prior = gauss_evaluate<T, 3>(d1, P0);
     T prop  = gauss_evaluate<T, 3>(d2, P);
+    if (sub != 0)
+    {
+        return;
+    }
     T w     = s.w[p];
     s.w[p]  = w * like * prior / prop;
 #pragma unroll
