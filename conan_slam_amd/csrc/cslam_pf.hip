@@ -268,6 +268,7 @@ struct Pf : PfBase
         return CSLAM_OK;
     }
 
+
     int use_device()
     {
         CSLAM_HIP_TRY(hipSetDevice(device));
@@ -470,7 +471,7 @@ struct Pf : PfBase
         }
         const T* R = static_cast<const T*>(Rv);
         hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np * kPfSubLanes + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(), m,
-                           R[0], R[1], R[2], R[3], dNormals());
+                           R[0], R[1], R[2], R[3], dNormals(), PfPredict<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0});
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -992,26 +993,37 @@ struct Pf : PfBase
         // (zero-copy -- the kernels reading the pinned slot over the host link -- was tried instead of this staged copy:
         // 13.7 k instead of 15.0 k steps/s)
         staged.clear();
+        // (a second stream for this copy, double-buffered inputs and event hand-overs so that it runs under the previous
+        // step's kernels was tried: 14.8 k instead of 16.7 k steps/s -- four more runtime calls per step cost more host
+        // time than the 10 us of stream time they free)
         CSLAM_HIP_TRY(hipMemcpyAsync(dObs, slot, bytes, hipMemcpyHostToDevice, stream));
         if ((rc = stage_commit()))
         {
             return rc;
         }
+        char*      base = reinterpret_cast<char*>(dObs);
+        const T*   sZ   = reinterpret_cast<const T*>(base);
+        const int* sIdf = reinterpret_cast<const int*>(base + off_idf());
+        const T*   sNrm = reinterpret_cast<const T*>(base + off_normals());
         const T* Q = static_cast<const T*>(Qv);
         const T* R = static_cast<const T*>(Rv);
-        hipLaunchKernelGGL(pf_predict_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), (T)v, (T)swa, Q[0],
-                           Q[1], Q[2], Q[3], (T)wb, (T)dt);
-        CSLAM_HIP_TRY(hipGetLastError());
-        if (m > 0)
+        if (m > 0) // predict rides inside the proposal kernel (which overwrites xv / Pv anyway)
         {
-            hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np * kPfSubLanes + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(),
-                               m, R[0], R[1], R[2], R[3], dNormals());
+            const PfPredict<T> pr{1, (T)v, (T)swa, Q[0], Q[1], Q[2], Q[3], (T)wb, (T)dt};
+            hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np * kPfSubLanes + 63) / 64), dim3(64), 0, stream, store(), sZ, sIdf,
+                               m, R[0], R[1], R[2], R[3], sNrm, pr);
             CSLAM_HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), dObs,
-                               dIdf(), m, R[0], R[1], R[2], R[3], (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1);
+            hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), sZ,
+                               sIdf, m, R[0], R[1], R[2], R[3], (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1);
             CSLAM_HIP_TRY(hipGetLastError());
         }
-        return launch_resample(reinterpret_cast<const T*>(reinterpret_cast<char*>(dObs) + off_sel), n_eff, status);
+        else
+        {
+            hipLaunchKernelGGL(pf_predict_kernel<T>, dim3((np + 63) / 64), dim3(64), 0, stream, store(), (T)v, (T)swa, Q[0],
+                               Q[1], Q[2], Q[3], (T)wb, (T)dt);
+            CSLAM_HIP_TRY(hipGetLastError());
+        }
+        return launch_resample(reinterpret_cast<const T*>(base + off_sel), n_eff, status);
     }
 
     int resample_stats(double* calls, double* resamples, double* last_neff) override

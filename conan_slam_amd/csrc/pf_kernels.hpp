@@ -39,6 +39,14 @@ struct PfStore
     int nf;
 };
 
+// a predict step riding inside pf_sample_proposal_kernel (on = 0: none)
+template <typename T>
+struct PfPredict
+{
+    int on;
+    T   v, swa, q00, q10, q01, q11, wb, dt;
+};
+
 // ---------------------------------------------------------------- tiny dense helpers (column-major)
 template <typename T, int RA, int CA, int CB>
 __device__ inline void mm(const T* A, const T* B, T* C)
@@ -475,25 +483,11 @@ __device__ inline void motion_jacobians(T phi, T v, T swa, T wb, T dt, T* Gv, T*
 }
 
 // ---------------------------------------------------------------- PF.cpp:419-471
+// PF::predict (PF.cpp:419-471) for one particle, in registers: X and P (column-major 3 x 3) in, predicted values out
 template <typename T>
-__global__ void __launch_bounds__(64) pf_predict_kernel(PfStore<T> s, T v, T swa, T q00, T q10, T q01, T q11, T wb, T dt)
+__device__ inline void pf_predict_state(T* X, T* P, T v, T swa, const T* Q, T wb, T dt)
 {
-    int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= s.np)
-    {
-        return;
-    }
-    T X[3], P[9], Gv[9], Gu[6], Q[4] = {q00, q10, q01, q11};
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-    {
-        X[i] = s.xv[(size_t)i * s.np + p];
-    }
-#pragma unroll
-    for (int i = 0; i < 9; i++)
-    {
-        P[i] = s.pv[(size_t)i * s.np + p];
-    }
+    T Gv[9], Gu[6];
     T phi = X[2];
     motion_jacobians<T>(phi, v, swa, wb, dt, Gv, Gu);
     T GvT[9], t1[9], t2[9], GuQ[6], GuT[6], t3[9];
@@ -506,11 +500,46 @@ __global__ void __launch_bounds__(64) pf_predict_kernel(PfStore<T> s, T v, T swa
 #pragma unroll
     for (int i = 0; i < 9; i++)
     {
-        s.pv[(size_t)i * s.np + p] = t2[i] + t3[i];
+        P[i] = t2[i] + t3[i];
     }
-    s.xv[(size_t)0 * s.np + p] = X[0] + v * dt * dcos(swa + phi);
-    s.xv[(size_t)1 * s.np + p] = X[1] + v * dt * dsin(swa + phi);
-    s.xv[(size_t)2 * s.np + p] = pi2pi<T>(X[2] + v * dt * dsin(swa) / wb);
+    const T x0 = X[0] + v * dt * dcos(swa + phi);
+    const T x1 = X[1] + v * dt * dsin(swa + phi);
+    const T x2 = pi2pi<T>(X[2] + v * dt * dsin(swa) / wb);
+    X[0]       = x0;
+    X[1]       = x1;
+    X[2]       = x2;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) pf_predict_kernel(PfStore<T> s, T v, T swa, T q00, T q10, T q01, T q11, T wb, T dt)
+{
+    int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= s.np)
+    {
+        return;
+    }
+    T X[3], P[9], Q[4] = {q00, q10, q01, q11};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+    {
+        X[i] = s.xv[(size_t)i * s.np + p];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+    {
+        P[i] = s.pv[(size_t)i * s.np + p];
+    }
+    pf_predict_state<T>(X, P, v, swa, Q, wb, dt);
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+    {
+        s.pv[(size_t)i * s.np + p] = P[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+    {
+        s.xv[(size_t)i * s.np + p] = X[i];
+    }
 }
 
 // ---------------------------------------------------------------- PF.cpp:382-417 -> slam.h:700-725 with n = 3, k = 1
@@ -610,8 +639,11 @@ constexpr int kPfSubLanes = 8; // lanes per particle in pf_sample_proposal_kerne
 template <typename T>
 __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, const T* __restrict__ Z,
                                                                  const int* __restrict__ idf, int m, T r00, T r10, T r01,
-                                                                 T r11, const T* __restrict__ normals)
+                                                                 T r11, const T* __restrict__ normals, PfPredict<T> pred)
 {
+    // pred.on: the particle's predict step (PF.cpp:419-471, pf_predict_state) is applied to the loaded pose and
+    // covariance first -- cslam_pf_observation_step's predict + observe in one launch; this kernel overwrites xv and Pv
+    // anyway, so the predicted values never go to memory
     // kPfSubLanes lanes per particle.  The sequential proposal updates (PF.cpp:502-530) are computed by all of them
     // alike (same instructions on the same values: lanes are free, a wave of 64 particles used 8 waves of the whole
     // chip); the m likelihood factors at the sampled pose (PF.cpp:343-359) are independent of one another, so sub-lane j
@@ -628,14 +660,27 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
 #pragma unroll
     for (int i = 0; i < 3; i++)
     {
-        X[i]  = s.xv[(size_t)i * s.np + p];
+        X[i] = s.xv[(size_t)i * s.np + p];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+    {
+        P[i] = s.pv[(size_t)i * s.np + p];
+    }
+    if (pred.on) // (kernel-uniform)
+    {
+        const T Q[4] = {pred.q00, pred.q10, pred.q01, pred.q11};
+        pf_predict_state<T>(X, P, pred.v, pred.swa, Q, pred.wb, pred.dt);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+    {
         X0[i] = X[i];
         PX[i] = X[i];
     }
 #pragma unroll
     for (int i = 0; i < 9; i++)
     {
-        P[i]  = s.pv[(size_t)i * s.np + p];
         P0[i] = P[i];
     }
     // The features of up to kObsChunk observations are requested together before the (strictly sequential) pose
