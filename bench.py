@@ -834,9 +834,10 @@ def pf_main(args):
     ws = sh.get_weights()
     if rank == 0:
         rec_bytes = (13 + 6 * Nf) * 4
-        # the resample's particle moves are the only HBM-heavy part: every kept record is read and written twice
-        # (gather through a scratch copy, pf_gather_rows_kernel): 4 x record x Np bytes per resampling step
-        moved = 4.0 * rec_bytes * Np * n_resampled
+        # the resample's particle moves are the only HBM-heavy part: every kept record is read once and written once
+        # into the twin store (pf_gather_move_kernel; single GPU) -- 2 x record x Np bytes per step, resampling or not
+        # (an identity copy otherwise); the sharded path packs / exchanges / unpacks only when it resamples
+        moved = 2.0 * rec_bytes * Np * (args.steps if world == 1 else n_resampled)
         out = {
             "metric": "pf_observation_steps_per_sec", "value": args.steps / elapsed, "unit": "PF observation steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -849,10 +850,10 @@ def pf_main(args):
                        "baseline_config": "BASELINE.json configs[3]"},
             "particle_obs_per_sec": args.steps * Np * m / elapsed,
             "weights_finite": bool(np.all(np.isfinite(ws))),
-            "roofline": {"kernel": "pf_gather_rows_kernel (resample moves)", "bound": "hbm", "unit": "GB/s",
+            "roofline": {"kernel": "pf_gather_move_kernel (resample moves)", "bound": "hbm", "unit": "GB/s",
                          "peak": HBM_PEAK_GBS, "achieved": moved / elapsed / 1e9,
                          "frac": moved / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "note": "whole-step average: algorithmic bytes of the particle moves (4 x record x Np per resample) "
+                         "note": "whole-step average: algorithmic bytes of the particle moves (2 x record x Np per step) "
                                  "/ step time; the step is a latency chain of small kernels, not bandwidth-bound "
                                  "(DESIGN.md 5)"},
         }

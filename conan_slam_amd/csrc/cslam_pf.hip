@@ -144,6 +144,11 @@ struct Pf : PfBase
     T*      dPv  = nullptr;
     T*      dXF  = nullptr;
     T*      dPF  = nullptr;
+    // the twin set the single-pass resample gathers into; the two sets are swapped after every resample call
+    T*      dXv2 = nullptr;
+    T*      dPv2 = nullptr;
+    T*      dXF2 = nullptr;
+    T*      dPF2 = nullptr;
     T*      dObs = nullptr; // staging: Z (2*mcap T) | idf (mcap int) | normals (3*np T), filled by one copy per call
     int*    dIdx = nullptr; // index lists of pack/unpack (max(mcap, np))
     double* dSums = nullptr;
@@ -193,6 +198,10 @@ struct Pf : PfBase
         (void)hipFree(dPv);
         (void)hipFree(dXF);
         (void)hipFree(dPF);
+        (void)hipFree(dXv2);
+        (void)hipFree(dPv2);
+        (void)hipFree(dXF2);
+        (void)hipFree(dPF2);
         (void)hipFree(dObs);
         (void)hipFree(dIdx);
         (void)hipFree(dSums);
@@ -330,6 +339,14 @@ struct Pf : PfBase
         CSLAM_HIP_TRY(hipMemsetAsync(dPv, 0, 9 * n1 * sizeof(T), stream));
         CSLAM_HIP_TRY(hipMemsetAsync(dXF, 0, 2 * cf * n1 * sizeof(T), stream));
         CSLAM_HIP_TRY(hipMemsetAsync(dPF, 0, 4 * cf * n1 * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMalloc(&dXv2, 3 * n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dPv2, 9 * n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dXF2, 2 * cf * n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMalloc(&dPF2, 4 * cf * n1 * sizeof(T)));
+        CSLAM_HIP_TRY(hipMemsetAsync(dXv2, 0, 3 * n1 * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPv2, 0, 9 * n1 * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dXF2, 0, 2 * cf * n1 * sizeof(T), stream));
+        CSLAM_HIP_TRY(hipMemsetAsync(dPF2, 0, 4 * cf * n1 * sizeof(T), stream));
         rc = ensure_m(64);
         if (rc)
         {
@@ -938,10 +955,17 @@ struct Pf : PfBase
         CSLAM_HIP_TRY(hipGetLastError());
         const dim3 ggrid(13 + 6 * store().nf, (np + 255) / 256);
         const T    w_new = (T)(1.0 / (double)np);
-        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 0>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable, w_new);
+        PfStore<T> twin  = store();
+        twin.xv          = dXv2;
+        twin.pv          = dPv2;
+        twin.xf          = dXF2;
+        twin.pf          = dPF2;
+        hipLaunchKernelGGL(pf_gather_move_kernel<T>, ggrid, dim3(256), 0, stream, store(), twin, dKeep, dEnable, w_new);
         CSLAM_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((pf_gather_rows_kernel<T, 1>), ggrid, dim3(256), 0, stream, store(), dKeep, dRec, dEnable, w_new);
-        CSLAM_HIP_TRY(hipGetLastError());
+        std::swap(dXv, dXv2); // the twin set is the store now (whether particles moved or were copied in place)
+        std::swap(dPv, dPv2);
+        std::swap(dXF, dXF2);
+        std::swap(dPF, dPF2);
         return CSLAM_OK;
     }
 

@@ -1240,6 +1240,55 @@ __global__ void __launch_bounds__(256) pf_exchange_plan_kernel(const int* __rest
 // slot i <- particle keep[i] for every row of the SoA store, through a scratch copy in the same layout: both passes
 // read and write along the particle index (coalesced), whereas the record form (pack/unpack: one block per particle)
 // strides by np between consecutive elements.  grid = (rows, ceil(np/256)); PASS 0: tmp <- gather, PASS 1: store <- tmp.
+// The same in ONE pass, from the store into its twin (cslam_pf.hip keeps two sets of xv / Pv / xf / Pf buffers and
+// swaps them after this kernel): dst slot i <- src particle keep[i] when the plan kernel decided to resample
+// (*enable), else <- src particle i (an identity copy costs what the two gated launches it replaces cost; the host
+// then knows which set is current without asking the device).  The weight row is not doubled: w = w_new in place when
+// resampling.  grid = (13 + 6 nf, ceil(np/256)).
+template <typename T>
+__global__ void __launch_bounds__(256) pf_gather_move_kernel(PfStore<T> s, PfStore<T> d, const int* __restrict__ keep,
+                                                             const int* __restrict__ enable, T w_new)
+{
+    const int en = *enable;
+    const int e  = blockIdx.x;
+    const int i  = blockIdx.y * 256 + threadIdx.x;
+    if (i >= s.np)
+    {
+        return;
+    }
+    if (e == 0)
+    {
+        if (en)
+        {
+            s.w[i] = w_new; // PF.cpp:495-499
+        }
+        return;
+    }
+    const T* src;
+    T*       dst;
+    if (e < 4)
+    {
+        src = s.xv + (size_t)(e - 1) * s.np;
+        dst = d.xv + (size_t)(e - 1) * s.np;
+    }
+    else if (e < 13)
+    {
+        src = s.pv + (size_t)(e - 4) * s.np;
+        dst = d.pv + (size_t)(e - 4) * s.np;
+    }
+    else if (e < 13 + 2 * s.nf)
+    {
+        src = s.xf + (size_t)(e - 13) * s.np;
+        dst = d.xf + (size_t)(e - 13) * s.np;
+    }
+    else
+    {
+        src = s.pf + (size_t)(e - 13 - 2 * s.nf) * s.np;
+        dst = d.pf + (size_t)(e - 13 - 2 * s.nf) * s.np;
+    }
+    dst[i] = src[en ? keep[i] : i];
+}
+
 template <typename T, int PASS>
 __global__ void __launch_bounds__(256) pf_gather_rows_kernel(PfStore<T> s, const int* __restrict__ keep, T* __restrict__ tmp,
                                                              const int* __restrict__ enable, T w_new)
