@@ -488,7 +488,7 @@ struct Pf : PfBase
         }
         const T* R = static_cast<const T*>(Rv);
         hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np * kPfSubLanes + 63) / 64), dim3(64), 0, stream, store(), dObs, dIdf(), m,
-                           R[0], R[1], R[2], R[3], dNormals(), PfPredict<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0});
+                           R[0], R[1], R[2], R[3], dNormals(), PfPredict<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0}, 0);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -1034,12 +1034,30 @@ struct Pf : PfBase
         if (m > 0) // predict rides inside the proposal kernel (which overwrites xv / Pv anyway)
         {
             const PfPredict<T> pr{1, (T)v, (T)swa, Q[0], Q[1], Q[2], Q[3], (T)wb, (T)dt};
+            // ... and so does the feature update, unless an observation list names a feature twice (the separate kernel
+            // then updates it twice from the same old value, last writer wins: kept as it was)
+            bool dup = false;
+            for (int a = 0; a < m && !dup; a++)
+            {
+                for (int c = a + 1; c < m; c++)
+                {
+                    if (idf[a] == idf[c])
+                    {
+                        dup = true;
+                        break;
+                    }
+                }
+            }
+            const int fu = dup ? 0 : ((quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 1 : 2);
             hipLaunchKernelGGL(pf_sample_proposal_kernel<T>, dim3((np * kPfSubLanes + 63) / 64), dim3(64), 0, stream, store(), sZ, sIdf,
-                               m, R[0], R[1], R[2], R[3], sNrm, pr);
+                               m, R[0], R[1], R[2], R[3], sNrm, pr, fu);
             CSLAM_HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), sZ,
-                               sIdf, m, R[0], R[1], R[2], R[3], (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1);
-            CSLAM_HIP_TRY(hipGetLastError());
+            if (fu == 0)
+            {
+                hipLaunchKernelGGL(pf_feature_update_kernel<T>, dim3((np + 63) / 64, m), dim3(64), 0, stream, store(), sZ,
+                                   sIdf, m, R[0], R[1], R[2], R[3], (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1);
+                CSLAM_HIP_TRY(hipGetLastError());
+            }
         }
         else
         {

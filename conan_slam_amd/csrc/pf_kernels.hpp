@@ -634,13 +634,73 @@ __global__ void __launch_bounds__(64) pf_heading_kernel(PfStore<T> s, T phi, T R
 
 // ---------------------------------------------------------------- PF.cpp:502-544 (+ 343-359, 279-317, 62-68)
 // normals: [3][np] standard-normal draws (input)
+// choleskyUpdate(XF, PF, V, R, HF) of one feature (slam.h:243-260 through PF.cpp:222-277): xf += W V, pf -= W1 W1^T
+template <typename T>
+__device__ inline void pf_feature_kf(const T* xf, const T* pf, const T* HF, const T* V, const T* R, int textbook, T* xf_new,
+                                     T* pf_new)
+{
+    // choleskyUpdate(XF, PF, V, R, HF): slam.h:243-260
+    T HFt[4], PHT[4], S[4], Lc[4], G[4], W1[4], Gt[4], W[4];
+    tr<T, 2, 2>(HF, HFt);
+    mm<T, 2, 2, 2>(pf, HFt, PHT);
+    mm<T, 2, 2, 2>(HF, PHT, S);
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+    {
+        S[e] = S[e] + R[e];
+    }
+    {
+        T o  = (S[1] + S[2]) * (T)0.5;
+        S[1] = o;
+        S[2] = o;
+        S[0] = (S[0] + S[0]) * (T)0.5;
+        S[3] = (S[3] + S[3]) * (T)0.5;
+    }
+    chol_decomp<T, 2>(S, Lc);
+    inverse_lu<T, 2>(Lc, G);
+    if (textbook)
+    {
+        T t0 = G[1];
+        G[1] = G[2];
+        G[2] = t0;
+    }
+    if (!all_finite<T, 2>(G))
+    {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            G[e] = (T)0;
+        }
+    }
+    mm<T, 2, 2, 2>(PHT, G, W1);
+    tr<T, 2, 2>(G, Gt);
+    mm<T, 2, 2, 2>(W1, Gt, W);
+    T dx[2];
+    mm<T, 2, 2, 1>(W, V, dx);
+    T W1t[4], WW[4];
+    tr<T, 2, 2>(W1, W1t);
+    mm<T, 2, 2, 2>(W1, W1t, WW);
+    xf_new[0] = xf[0] + dx[0];
+    xf_new[1] = xf[1] + dx[1];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+    {
+        pf_new[e] = pf[e] - WW[e];
+    }
+}
+
 constexpr int kPfSubLanes = 8; // lanes per particle in pf_sample_proposal_kernel (= its observation chunk)
 
 template <typename T>
 __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, const T* __restrict__ Z,
                                                                  const int* __restrict__ idf, int m, T r00, T r10, T r01,
-                                                                 T r11, const T* __restrict__ normals, PfPredict<T> pred)
+                                                                 T r11, const T* __restrict__ normals, PfPredict<T> pred,
+                                                                 int fu_mode)
 {
+    // fu_mode != 0: PF::featureUpdate (PF.cpp:222-277) of the m observed features rides along too (1: the reference's
+    // gain, 2: the textbook one): it needs exactly the Jacobians and innovation at the SAMPLED pose that the likelihood
+    // factor of the same observation is built from, so the sub-lane that has them finishes the feature's Kalman update
+    // and stores it (pf_feature_update_kernel would reload the pose and the feature and recompute them)
     // pred.on: the particle's predict step (PF.cpp:419-471, pf_predict_state) is applied to the loaded pose and
     // covariance first -- cslam_pf_observation_step's predict + observe in one launch; this kernel overwrites xv and Pv
     // anyway, so the predicted values never go to memory
@@ -780,6 +840,19 @@ __global__ void __launch_bounds__(64) pf_sample_proposal_kernel(PfStore<T> s, co
             V[0] = Z[2 * i] - ZP[0];
             V[1] = pi2pi<T>(Z[2 * i + 1] - ZP[1]);
             lf   = gauss_evaluate<T, 2>(V, SF);
+            if (fu_mode != 0 && base + sub < m)
+            {
+                T xn[2], pn[4];
+                pf_feature_kf<T>(xf, pf, HF, V, R, fu_mode == 2 ? 1 : 0, xn, pn);
+                const int f = idf[i] - 1;
+                s.xf[((size_t)f * 2 + 0) * s.np + p] = xn[0];
+                s.xf[((size_t)f * 2 + 1) * s.np + p] = xn[1];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    s.pf[((size_t)f * 4 + e) * s.np + p] = pn[e];
+                }
+            }
         }
         const int lane0 = (int)(threadIdx.x & ~(kPfSubLanes - 1));
 #pragma unroll
@@ -839,53 +912,14 @@ __global__ void __launch_bounds__(64) pf_feature_update_kernel(PfStore<T> s, con
     compute_jacobians<T>(X, xf, pf, R, ZP, HV, HF, SF);
     V[0] = Z[2 * i] - ZP[0];
     V[1] = pi2pi<T>(Z[2 * i + 1] - ZP[1]);
-    // choleskyUpdate(XF, PF, V, R, HF): slam.h:243-260
-    T HFt[4], PHT[4], S[4], Lc[4], G[4], W1[4], Gt[4], W[4];
-    tr<T, 2, 2>(HF, HFt);
-    mm<T, 2, 2, 2>(pf, HFt, PHT);
-    mm<T, 2, 2, 2>(HF, PHT, S);
+    T xn[2], pn[4];
+    pf_feature_kf<T>(xf, pf, HF, V, R, textbook, xn, pn);
+    s.xf[((size_t)f * 2 + 0) * s.np + p] = xn[0];
+    s.xf[((size_t)f * 2 + 1) * s.np + p] = xn[1];
 #pragma unroll
     for (int e = 0; e < 4; e++)
     {
-        S[e] = S[e] + R[e];
-    }
-    {
-        T o  = (S[1] + S[2]) * (T)0.5;
-        S[1] = o;
-        S[2] = o;
-        S[0] = (S[0] + S[0]) * (T)0.5;
-        S[3] = (S[3] + S[3]) * (T)0.5;
-    }
-    chol_decomp<T, 2>(S, Lc);
-    inverse_lu<T, 2>(Lc, G);
-    if (textbook)
-    {
-        T t0 = G[1];
-        G[1] = G[2];
-        G[2] = t0;
-    }
-    if (!all_finite<T, 2>(G))
-    {
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-        {
-            G[e] = (T)0;
-        }
-    }
-    mm<T, 2, 2, 2>(PHT, G, W1);
-    tr<T, 2, 2>(G, Gt);
-    mm<T, 2, 2, 2>(W1, Gt, W);
-    T dx[2];
-    mm<T, 2, 2, 1>(W, V, dx);
-    T W1t[4], WW[4];
-    tr<T, 2, 2>(W1, W1t);
-    mm<T, 2, 2, 2>(W1, W1t, WW);
-    s.xf[((size_t)f * 2 + 0) * s.np + p] = xf[0] + dx[0];
-    s.xf[((size_t)f * 2 + 1) * s.np + p] = xf[1] + dx[1];
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-    {
-        s.pf[((size_t)f * 4 + e) * s.np + p] = pf[e] - WW[e];
+        s.pf[((size_t)f * 4 + e) * s.np + p] = pn[e];
     }
 }
 
