@@ -1271,11 +1271,9 @@ __global__ void __launch_bounds__(256) pf_exchange_plan_kernel(const int* __rest
     }
 }
 
-// slot i <- particle keep[i] for every row of the SoA store, through a scratch copy in the same layout: both passes
-// read and write along the particle index (coalesced), whereas the record form (pack/unpack: one block per particle)
-// strides by np between consecutive elements.  grid = (rows, ceil(np/256)); PASS 0: tmp <- gather, PASS 1: store <- tmp.
-// The same in ONE pass, from the store into its twin (cslam_pf.hip keeps two sets of xv / Pv / xf / Pf buffers and
-// swaps them after this kernel): dst slot i <- src particle keep[i] when the plan kernel decided to resample
+// The particle moves of a resample in ONE pass along the particle index (coalesced both ways), from the store into its
+// twin (cslam_pf.hip keeps two sets of xv / Pv / xf / Pf buffers and swaps them after this kernel; the first form went
+// through a scratch copy and back in two gated launches): dst slot i <- src particle keep[i] when the plan kernel decided to resample
 // (*enable), else <- src particle i (an identity copy costs what the two gated launches it replaces cost; the host
 // then knows which set is current without asking the device).  The weight row is not doubled: w = w_new in place when
 // resampling.  grid = (13 + 6 nf, ceil(np/256)).
@@ -1323,51 +1321,6 @@ __global__ void __launch_bounds__(256) pf_gather_move_kernel(PfStore<T> s, PfSto
     dst[i] = src[en ? keep[i] : i];
 }
 
-template <typename T, int PASS>
-__global__ void __launch_bounds__(256) pf_gather_rows_kernel(PfStore<T> s, const int* __restrict__ keep, T* __restrict__ tmp,
-                                                             const int* __restrict__ enable, T w_new)
-{
-    // w_new (PASS 1): the weight every resampled particle gets (PF.cpp:495-499) -- row 0 is written with it directly
-    if (*enable == 0)
-    {
-        return;
-    }
-    const int e = blockIdx.x;
-    const int i = blockIdx.y * 256 + threadIdx.x;
-    if (i >= s.np)
-    {
-        return;
-    }
-    T* row;
-    if (e == 0)
-    {
-        row = s.w;
-    }
-    else if (e < 4)
-    {
-        row = s.xv + (size_t)(e - 1) * s.np;
-    }
-    else if (e < 13)
-    {
-        row = s.pv + (size_t)(e - 4) * s.np;
-    }
-    else if (e < 13 + 2 * s.nf)
-    {
-        row = s.xf + (size_t)(e - 13) * s.np;
-    }
-    else
-    {
-        row = s.pf + (size_t)(e - 13 - 2 * s.nf) * s.np;
-    }
-    if (PASS == 0)
-    {
-        tmp[(size_t)e * s.np + i] = row[keep[i]];
-    }
-    else
-    {
-        row[i] = (e == 0) ? w_new : tmp[(size_t)e * s.np + i];
-    }
-}
 
 template <typename T>
 __global__ void __launch_bounds__(256) pf_set_weights_if_kernel(T* __restrict__ w, int np, T value, const int* __restrict__ enable)
