@@ -624,6 +624,12 @@ def mc_main(args):
         e = EKF(N, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
         e.set_state(w.X0, w.P0)
         e.set_pgemm_workgroups(max(32, 512 // I) if args.pgemm_wgs < 0 else args.pgemm_wgs)
+        if args.defer < 0:
+            # as the headline: one k = 128 P-GEMM per two updates -- 3.5 launches per step instead of 4, and the runs are
+            # launch-bound (measured on one GPU: 34.8 k / 38.4 k / 33.3 k aggregate steps/s with windows of 0 / 128 / 256)
+            args.defer = 128 if (args.dtype == "f32" and 2 * m == 64) else 0
+        if args.defer > 0:
+            e.set_deferred(args.defer)
         w.P0 = None
         inp = DeviceInputs(torch, w, 2 * total)
         engs.append(e)
@@ -697,12 +703,14 @@ def mc_main(args):
         "config": {"workload": f"{world * I} independent Monte-Carlo EKF-SLAM runs x {N} landmarks (n={n}), m={m} (k={2 * m}), "
                                f"{args.dtype}, {I} runs per GPU, one stream pair + one host thread per run",
                    "landmarks": N, "n": n, "obs_per_update": m, "instances_per_gpu": I, "gain_algebra": args.quirks,
+                   "deferred_columns": args.defer,
                    "parallelism": f"{I} instances/GPU x {world} GPU(s), no collective",
                    "baseline_config": "BASELINE.json configs[4]" if (N, I * max(world, 1)) == (2000, 64) or N == 2000 else "custom"},
         "single_instance": {"value": args.steps / el1, "unit": "update steps/s", "ms_per_step": el1 / args.steps * 1e3,
                             "note": "one of the instances run alone on the same GPU (same driver)"},
         "concurrency_gain": (I * args.steps / elapsed) / (args.steps / el1) if world == 1 else None,
-        "roofline": roofline_record(n, 2 * m, args.dtype, storage, dd_s, dd_cnt, N,
+        "roofline": roofline_record(n, (2 * m) * max(1, args.defer // (2 * m)) if args.defer > 0 else 2 * m, args.dtype, storage,
+                                    dd_s, dd_cnt, N,
                                     {"note": "P-GEMM launches of all instances (sampled 1 in 16), co-running with the "
                                              "other instances' kernels"}),
         "factor_flags": flags,
