@@ -45,6 +45,7 @@ struct EkfBase
     int         dtype    = CSLAM_F32;
     int         fuse_f64 = 1; // the f64 MFMA kernels take a held predict too (env CSLAM_FUSE_F64=0: its own launch)
     int         pgemm_limbs_req = -1, limbs_kmin_req = -1; // env CSLAM_PGEMM_LIMBS / CSLAM_LIMBS_KMIN (-1: default)
+    int         xcd_queues_req = -1;                       // env CSLAM_XCD_QUEUES
     int         device   = 0;
     int         quirks   = CSLAM_Q_REF_EXACT;
     int         nmax     = 0; // max landmarks
@@ -148,6 +149,11 @@ struct Ekf : EkfBase
     // Off by default: correct and as accurate as the f32 MFMA kernel (tests), but measured no faster -- 120 - 132 us
     // against 115 at k = 128, N = 5000 -- see DESIGN.md 8.
     int        pgemm_limbs = 0;
+    // the f32 P-GEMM draws its tiles from one queue per XCD over a Morton-ordered list (env CSLAM_XCD_QUEUES=1).  Off by
+    // default: it cuts the HBM fetch traffic of a launch by a sixth (k = 64: 487 -> 435 MB, 1.04x the algorithmic bytes;
+    // k = 128: 584 -> 483 MB) but not its time (81.7 vs 80.9 us, 115.3 vs 114.6 us), and the loops built on it came out
+    // 0 - 4 % slower (profiles/r02_pmc_xcd_queues.txt)
+    int        xcd_queues  = 0;
     int        limbs_kmin  = 65;
     uint4*     dWb         = nullptr;
     size_t     wb_bytes    = 0;
@@ -283,6 +289,10 @@ struct Ekf : EkfBase
         if (rc)
         {
             return rc;
+        }
+        if (xcd_queues_req >= 0)
+        {
+            xcd_queues = xcd_queues_req;
         }
         if (pgemm_limbs_req >= 0)
         {
@@ -597,6 +607,59 @@ struct Ekf : EkfBase
             }
             hd_cols[wcur] = 0;
         }
+        return CSLAM_OK;
+    }
+
+    // the tile list in Morton order, cut into eight equal segments (one per XCD), and the 2 x 8 ticket counters
+    int ensure_tiles_morton(int tiles, hipStream_t stream)
+    {
+        if (tilesM_built == tiles)
+        {
+            return CSLAM_OK;
+        }
+
+        // Morton order over the lower triangle, eight equal segments
+        auto spread = [](unsigned v) {
+            v &= 0xFFFF;
+            v = (v | (v << 8)) & 0x00FF00FF;
+            v = (v | (v << 4)) & 0x0F0F0F0F;
+            v = (v | (v << 2)) & 0x33333333;
+            v = (v | (v << 1)) & 0x55555555;
+            return v;
+        };
+        std::vector<std::pair<unsigned, int2>> keyed;
+        keyed.reserve((size_t)tiles * (tiles + 1) / 2);
+        for (int tj = 0; tj < tiles; tj++)
+        {
+            for (int ti = tj; ti < tiles; ti++)
+            {
+                keyed.push_back({spread((unsigned)ti) | (spread((unsigned)tj) << 1), make_int2(ti, tj)});
+            }
+        }
+        std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        std::vector<int2> hl(keyed.size());
+        for (size_t i = 0; i < keyed.size(); i++)
+        {
+            hl[i] = keyed[i].second;
+        }
+        int off[9];
+        for (int sgi = 0; sgi <= 8; sgi++)
+        {
+            off[sgi] = (int)((size_t)hl.size() * sgi / 8);
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(dTilesM);
+        dTilesM = nullptr;
+        CSLAM_HIP_TRY(hipMalloc(&dTilesM, hl.size() * sizeof(int2)));
+        CSLAM_HIP_TRY(hipMemcpy(dTilesM, hl.data(), hl.size() * sizeof(int2), hipMemcpyHostToDevice));
+        if (dSegOff == nullptr)
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dSegOff, 9 * sizeof(int)));
+            CSLAM_HIP_TRY(hipMalloc(&dTicketX, 16 * sizeof(int)));
+            CSLAM_HIP_TRY(hipMemset(dTicketX, 0, 16 * sizeof(int)));
+        }
+        CSLAM_HIP_TRY(hipMemcpy(dSegOff, off, sizeof(off), hipMemcpyHostToDevice));
+        tilesM_built = tiles;
         return CSLAM_OK;
     }
 
@@ -1885,50 +1948,9 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
                 CSLAM_HIP_TRY(hipMalloc(&dWb, cap));
                 wb_bytes = cap;
             }
-            if (tilesM_built != tiles)
+            if ((rc = ensure_tiles_morton(tiles, stream)))
             {
-                // Morton order over the lower triangle, eight equal segments
-                auto spread = [](unsigned v) {
-                    v &= 0xFFFF;
-                    v = (v | (v << 8)) & 0x00FF00FF;
-                    v = (v | (v << 4)) & 0x0F0F0F0F;
-                    v = (v | (v << 2)) & 0x33333333;
-                    v = (v | (v << 1)) & 0x55555555;
-                    return v;
-                };
-                std::vector<std::pair<unsigned, int2>> keyed;
-                keyed.reserve((size_t)tiles * (tiles + 1) / 2);
-                for (int tj = 0; tj < tiles; tj++)
-                {
-                    for (int ti = tj; ti < tiles; ti++)
-                    {
-                        keyed.push_back({spread((unsigned)ti) | (spread((unsigned)tj) << 1), make_int2(ti, tj)});
-                    }
-                }
-                std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-                std::vector<int2> hl(keyed.size());
-                for (size_t i = 0; i < keyed.size(); i++)
-                {
-                    hl[i] = keyed[i].second;
-                }
-                int off[9];
-                for (int sgi = 0; sgi <= 8; sgi++)
-                {
-                    off[sgi] = (int)((size_t)hl.size() * sgi / 8);
-                }
-                CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-                (void)hipFree(dTilesM);
-                dTilesM = nullptr;
-                CSLAM_HIP_TRY(hipMalloc(&dTilesM, hl.size() * sizeof(int2)));
-                CSLAM_HIP_TRY(hipMemcpy(dTilesM, hl.data(), hl.size() * sizeof(int2), hipMemcpyHostToDevice));
-                if (dSegOff == nullptr)
-                {
-                    CSLAM_HIP_TRY(hipMalloc(&dSegOff, 9 * sizeof(int)));
-                    CSLAM_HIP_TRY(hipMalloc(&dTicketX, 16 * sizeof(int)));
-                    CSLAM_HIP_TRY(hipMemset(dTicketX, 0, 16 * sizeof(int)));
-                }
-                CSLAM_HIP_TRY(hipMemcpy(dSegOff, off, sizeof(off), hipMemcpyHostToDevice));
-                tilesM_built = tiles;
+                return rc;
             }
             hipLaunchKernelGGL(ekf_limb_split_kernel, dim3((rows + 255) / 256, kgs), dim3(256), 0, stream, W, ldp, k, rows, kgs,
                                dWb);
@@ -1977,11 +1999,25 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
         {
             // every memory operation interleaved with the MFMA loop; two (k <= 64) or four (k <= 128) chunks of 32
             launch_parity++;
+            // per-XCD tile queues (see the kernel): env CSLAM_XCD_QUEUES
+            // (every queue needs workgroups: small grids stay on the single queue)
+            const bool xq = xcd_queues != 0 && dHwIds == nullptr && G >= 64;
+            if (xq)
+            {
+                if ((rc = ensure_tiles_morton(tiles, stream)))
+                {
+                    return rc;
+                }
+                limb_parity ^= 1;
+            }
             const bool nt     = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
             const int  ntmode = psym_nt >= 0 ? psym_nt : (nt ? 1 : 0);
 #define CSLAM_LAUNCH_PSYM4X(MODE, NCH, KC, PF)                                                                        \
     hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE, NCH, KC, PF>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k,     \
-                       dTiles, n_sym_tiles, dTicket + (launch_parity & 1), dTicket + ((launch_parity + 1) & 1), dHwIds)
+                       xq ? (const int2*)dTilesM : (const int2*)dTiles, n_sym_tiles,                                  \
+                       xq ? dTicketX + 8 * limb_parity : dTicket + (launch_parity & 1),                              \
+                       xq ? dTicketX + 8 * (limb_parity ^ 1) : dTicket + ((launch_parity + 1) & 1), dHwIds,          \
+                       xq ? (const int*)dSegOff : (const int*)nullptr)
 #define CSLAM_LAUNCH_PSYM4(MODE, NCH) CSLAM_LAUNCH_PSYM4X(MODE, NCH, 32, false)
             // software-pipelined LDS operands (see the kernel): an A/B switch, CSLAM_PSYM_PREFETCH=1
             // (measured, N = 5000: k = 128 119.3 vs 119.4 us, k = 64 80.6 vs 85.5 us without / with: two waves per SIMD
@@ -2354,6 +2390,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* pv = getenv("CSLAM_PIPELINE"))
     {
         b->pipeline = atoi(pv) ? 1 : 0;
+    }
+    if (const char* xv = getenv("CSLAM_XCD_QUEUES"))
+    {
+        b->xcd_queues_req = atoi(xv) ? 1 : 0;
     }
     if (const char* lv = getenv("CSLAM_PGEMM_LIMBS"))
     {

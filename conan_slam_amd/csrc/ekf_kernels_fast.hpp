@@ -3561,9 +3561,21 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
 template <int NTMODE, int NCH, int KC = 32, bool PF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
-                       const int2* __restrict__ tile_list, int ntiles, int* __restrict__ ticket,
-                       int* __restrict__ ticket_reset, unsigned long long* __restrict__ hwids)
+                       const int2* __restrict__ tile_list_in, int ntiles_in, int* __restrict__ ticket_in,
+                       int* __restrict__ ticket_reset, unsigned long long* __restrict__ hwids,
+                       const int* __restrict__ seg_off = nullptr)
 {
+    // seg_off != nullptr: one tile queue per XCD.  tile_list_in is then Morton-ordered and cut into eight segments
+    // (seg_off[0..8]), ticket_in / ticket_reset are eight counters each, and workgroup b works on queue b & 7 -- its
+    // first two tiles by its rank b >> 3 in that queue, the rest by tickets -- exactly as on the single queue.  Blocks
+    // are dealt round-robin over the XCDs (b and b + 8 share one), so each L2 sees one compact patch of the triangle and
+    // the W1 panels of a few block rows and columns instead of all of them.  Placement is a speed matter only: queue
+    // membership is by block index, every queue has its workgroups whatever the hardware does with them.
+    const bool xq = seg_off != nullptr; // (kernel-uniform)
+    const int  qid = xq ? (int)(blockIdx.x & 7u) : 0;
+    const int2* tile_list = xq ? tile_list_in + seg_off[qid] : tile_list_in;
+    const int   ntiles    = xq ? seg_off[qid + 1] - seg_off[qid] : ntiles_in;
+    int*        ticket    = xq ? ticket_in + qid : ticket_in;
     static_assert(KC % 8 == 0 && KC / 2 >= ((NCH == 2) ? 16 : 8), "chunk depth: DMA granularity 8, room for the memory-op schedule");
     // four separate LDS objects (not one array): the compiler's wait-count pass can then tell that the panel
     // DMA in flight (other chunk's buffers) does not alias the buffers the MFMA loop is reading
@@ -3578,7 +3590,7 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
     const int lane = tid & 63;
     const int lj   = lane & 31;
     const int lh   = lane >> 5;
-    const int G    = gridDim.x;
+    const int G    = xq ? (int)((gridDim.x - (blockIdx.x & 7u) + 7u) >> 3) : (int)gridDim.x; // workgroups on this queue
 
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -3787,10 +3799,10 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
         return have_next;
     };
 
-    int t = blockIdx.x;
-    if (t == 0 && tid == 0)
+    const int t = xq ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; // rank on the queue
+    if (blockIdx.x == 0 && tid < (xq ? 8 : 1))
     {
-        *ticket_reset = 0; // the counter the NEXT launch on this stream will use
+        ticket_reset[tid] = 0; // the counter(s) the NEXT launch on this stream will use
     }
     if (t >= ntiles)
     {
