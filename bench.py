@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--sequential", action="store_true", help="batch=false (EKF.cpp:457-479)")
     ap.add_argument("--defer", type=int, default=-1,
                     help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = every update at once; "
-                         "default: 128 for the f32 headline -- one P-GEMM per two updates --, else 0)")
+                         "default: 128 for batches of 32 observations -- one P-GEMM per two updates --, else 0)")
     ap.add_argument("--instances", type=int, default=8, help="mc: filter instances per GPU")
     ap.add_argument("--pgemm-wgs", type=int, default=-1,
                     help="mc: cap on each instance's persistent P-GEMM grid (-1: 512 / instances, 0: whole chip)")
@@ -336,7 +336,8 @@ def ekf_main(args):
     if args.defer < 0:
         # the engine's deferred-downdate mode (P = Ps - Wp Wp^T; every update is applied to the state, and to the
         # covariance through the pending-panel correction): one k = 128 P-GEMM per two updates moves P half as often
-        args.defer = 128 if (args.dtype == "f32" and not args.sequential and 2 * args.obs == 64) else 0
+        # (f64 at N = 1000 gains less from it -- 15 930 vs 15 740 steps/s -- its P-GEMM being latency-bound either way)
+        args.defer = 128 if (not args.sequential and 2 * args.obs == 64) else 0
     if args.defer > 0:
         eng.set_deferred(args.defer)
     n_imm = args.steps if (extras and args.defer > 0) else 0

@@ -2232,8 +2232,9 @@ template <>
 int Ekf<double>::launch_downdate(const double* W, int k, hipStream_t stream)
 {
     const int tiles_r = round_up(n, kTile) / kTile;
-    // columns of W1 staged per pass: 16 (several workgroups per CU).  Measured at N = 1000, k = 64: 8 / 16 / 32 -> 22.8 / 21.9 /
-    // 22.9 us, 64 (the whole panel at once, 96 KB of LDS, one workgroup per CU) -> 30.5 us.  CSLAM_F64_KCM overrides.
+    // columns of W1 staged per pass: 16, register-staged and double-buffered (see the kernel).  The synchronous staging
+    // loop (other values of CSLAM_F64_KCM) measured at N = 1000, k = 64: 8 / 16 / 32 -> 22.8 / 21.9 / 22.9 us, 64 (the whole
+    // panel at once, 96 KB of LDS, one workgroup per CU) -> 30.5 us.
     int kcm = 16;
     if (const char* e = getenv("CSLAM_F64_KCM"))
     {
@@ -2246,7 +2247,7 @@ int Ekf<double>::launch_downdate(const double* W, int k, hipStream_t stream)
         cb = (atoi(e) == 2) ? 2 : 4;
     }
     const int tiles_c = round_up(n, kTile) / (16 * cb);
-    const size_t lds  = (size_t)kcm * (128 + 16 * cb) * sizeof(double);
+    const size_t lds  = (size_t)(kcm == 16 ? 2 : 1) * kcm * (128 + 16 * cb) * sizeof(double); // (16: two buffers)
     if (cb == 2)
     {
         hipLaunchKernelGGL(ekf_downdate_f64<2>, dim3(tiles_r * tiles_c), dim3(256), lds, stream, dP, ldp, W, ldp, k, tiles_r, lower,

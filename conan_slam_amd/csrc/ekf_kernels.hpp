@@ -1415,6 +1415,80 @@ __global__ void __launch_bounds__(256, 2) ekf_downdate_f64(double* __restrict__ 
             v[cb * 4 + g]   = *ptr[cb * 4 + g];
         }
     }
+    if (kcm == 16)
+    {
+        // Register-staged, double-buffered panels: the loads of pass p+1 are in flight while pass p is multiplied, and
+        // one barrier per pass is enough (pass p+2 overwrites buffer p & 1 only behind the barrier of pass p+1, which
+        // every wave reaches after it has finished reading pass p).  The first form of this loop -- load, store to LDS,
+        // barrier, multiply, barrier, per pass and per staging iteration -- cost 13 us per 64 columns (five dependent
+        // round trips per pass) where the MFMAs need 1.
+        constexpr int KCM = 16;
+        constexpr int NRB = KCM * 64 / 256;                   // row-panel double2 per thread (4)
+        constexpr int NRA = (KCM * (TC / 2) + 255) / 256;     // column-panel double2 per thread (1 or 2)
+        double2       rb[NRB], ra[NRA];
+        auto fetch = [&](int k0) {
+            const int kc = min(KCM, k - k0);
+#pragma unroll
+            for (int it = 0; it < NRB; it++)
+            {
+                const int id = tid + it * 256;
+                const int kk = id >> 6, r2 = (id & 63) * 2;
+                rb[it] = (kk < kc) ? *reinterpret_cast<const double2*>(W1 + (size_t)(k0 + kk) * ldw + row0 + r2)
+                                   : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int it = 0; it < NRA; it++)
+            {
+                const int id = tid + it * 256;
+                const int kk = id / (TC / 2), r2 = (id % (TC / 2)) * 2;
+                ra[it] = (kk < kc && kk < KCM) ? *reinterpret_cast<const double2*>(W1 + (size_t)(k0 + kk) * ldw + col0 + r2)
+                                               : make_double2(0.0, 0.0);
+            }
+        };
+        constexpr int kBuf = KCM * (128 + TC); // doubles per buffer (the launch provides two)
+        fetch(0);
+        int par = 0;
+        for (int k0 = 0; k0 < k; k0 += KCM, par ^= 1)
+        {
+            double* bB = s_pan + par * kBuf;
+            double* bA = bB + KCM * 128;
+#pragma unroll
+            for (int it = 0; it < NRB; it++)
+            {
+                const int id = tid + it * 256;
+                *reinterpret_cast<double2*>(&bB[(id >> 6) * 128 + (id & 63) * 2]) = rb[it];
+            }
+#pragma unroll
+            for (int it = 0; it < NRA; it++)
+            {
+                const int id = tid + it * 256;
+                if (id < KCM * (TC / 2))
+                {
+                    *reinterpret_cast<double2*>(&bA[(id / (TC / 2)) * TC + (id % (TC / 2)) * 2]) = ra[it];
+                }
+            }
+            if (k0 + KCM < k)
+            {
+                fetch(k0 + KCM);
+            }
+            __syncthreads();
+            // (rows of the panel beyond k were stored as zeros: every pass is KCM deep)
+#pragma unroll
+            for (int kk = 0; kk < KCM; kk += 4)
+            {
+                const int     kq = kk + lq;
+                const double2 b  = *reinterpret_cast<const double2*>(&bB[kq * 128 + wave * 32 + 2 * lj]);
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+                {
+                    const double a = bA[kq * TC + cb * 16 + lj];
+                    acc[0][cb]     = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.x, acc[0][cb], 0, 0, 0);
+                    acc[1][cb]     = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.y, acc[1][cb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    else
     for (int k0 = 0; k0 < k; k0 += kcm)
     {
         const int kc = min(kcm, k - k0);
