@@ -239,6 +239,13 @@ def pgemm_model(n, k_launch, dname, storage):
     s = 4 if dname == "f32" else 8
     k8 = ((int(round(k_launch)) + 7) // 8) * 8
     full_bytes = 2.0 * n * n * s + 1.0 * n * k_launch * s  # full-storage P read + written, W1 read once
+    if storage == "lower" and dname == "f64":
+        # ekf_downdate_f64: 128-row tiles on or below the block diagonal are read and written once (the others leave at
+        # once), W1 once; passes of 16 columns
+        nt = sym_tiles(n)
+        depth = (k8 + 15) // 16 * 16
+        return {"kernel": "ekf_downdate_f64<2>", "bytes": nt * 128.0 * 128.0 * s * 2 + 1.0 * n * k8 * s,
+                "flops_issued": nt * 128.0 * 128.0 * depth * 2, "full_storage_bytes": full_bytes, "n_sym_tiles": nt}
     if storage == "lower":
         nt = sym_tiles(n)
         depth = 64 if k8 <= 64 else (96 if k8 <= 96 else (128 if k8 <= 128 else (k8 + 63) // 64 * 64))  # chunks x chunk depth
@@ -290,7 +297,7 @@ def roofline_record(n, k_launch, dname, storage, launch_s, launches, landmarks, 
         "traffic": traffic,
         "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if traffic else None,
         "algorithmic_bytes_per_launch": md["bytes"],
-        "bytes_model": ("block-lower symmetric storage: n_sym_tiles x 64 KiB read + written once, W1 panel (n x k8) read once"
+        "bytes_model": ("block-lower symmetric storage: n_sym_tiles x (128 x 128 x s bytes) read + written once, W1 panel (n x k8) read once"
                         if storage == "lower" else "full storage: 2 n^2 s + n k s (SURVEY 8d)"),
         "n_sym_tiles": md["n_sym_tiles"],
         "launch_us": launch_s * 1e6 if launch_s else None, "launches_timed": launches, "k_per_launch": k_launch,
@@ -390,8 +397,8 @@ def ekf_main(args):
             dist.destroy_process_group()
         return
 
-    storage = "full" if (os.environ.get("CSLAM_STORAGE") == "full" or args.dtype == "f64" or
-                         os.environ.get("CSLAM_TUNE_DOWNDATE", "0") not in ("0", "2", "3")) else "lower"
+    storage = "full" if (os.environ.get("CSLAM_STORAGE") == "full" or
+                         (args.dtype == "f32" and os.environ.get("CSLAM_TUNE_DOWNDATE", "0") not in ("0", "2", "3"))) else "lower"
     dd_ms, dd_cnt = stages["downdate"]
     dd_s = (dd_ms / dd_cnt) * 1e-3 if dd_cnt else None
     # columns one P-GEMM launch applies: k, or (explicit deferral / sequential) the pending columns of several updates
@@ -696,7 +703,7 @@ def mc_main(args):
     dd_ms = sum(d[0] for d in dd)
     dd_cnt = sum(d[1] for d in dd)
     dd_s = dd_ms / dd_cnt * 1e-3 if dd_cnt else None
-    storage = "lower" if args.dtype == "f32" and os.environ.get("CSLAM_STORAGE") != "full" else "full"
+    storage = "lower" if os.environ.get("CSLAM_STORAGE") != "full" else "full"
     out = {
         "metric": "ekf_update_steps_per_sec", "value": world * I * args.steps / elapsed, "unit": "update steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
