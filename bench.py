@@ -802,7 +802,10 @@ def pf_main(args):
         sh.set_particle(i, 1.0 / Np, pose, Pv, XF, PF)
     from conan_slam_amd.pf import RcclComm
 
-    comm = RcclComm(local_rank) if world > 1 else SingleComm()
+    if world > 1 and _REHEARSE:
+        comm = TorchComm()  # one-GPU rehearsal: RCCL refuses one device twice, the planner runs over gloo instead
+    else:
+        comm = RcclComm(local_rank) if world > 1 else SingleComm()
     total = args.warmup + args.steps
     inputs = []
     for t in range(total):
