@@ -804,3 +804,33 @@ def test_limb_pgemm_matches_the_f32_mfma_pgemm(gpu_required, monkeypatch, limbs,
     assert_close("P", P1, P0, 3e-5)
     assert abs(float(np.trace(P1.astype(np.float64))) - float(np.trace(P0.astype(np.float64)))) <= 2e-6 * float(
         np.trace(P0.astype(np.float64)))
+
+
+def test_per_xcd_tile_queues_change_nothing_but_the_order(gpu_required, monkeypatch):
+    """CSLAM_XCD_QUEUES=1 (one tile queue per XCD over a Morton-ordered list) hands the same tiles to the same kernel in
+    another order: the filter must come out bit for bit as with the single queue (N = 3000: 1 128 tiles, k = 64 and
+    k = 128 launches)."""
+    from conan_slam_amd import EKF
+    from conan_slam_amd.synth import Workload
+
+    N = 3000
+    w = Workload(N, 32, np.float32)
+    steps = [(w.controls(t), w.observations(t)) for t in range(5)]
+
+    def run(queues, defer):
+        monkeypatch.setenv("CSLAM_XCD_QUEUES", str(queues))
+        e = EKF(N, dtype=np.float32, quirks=TEXTBOOK)
+        e.set_state(w.X0, w.P0)
+        e.set_deferred(defer)
+        for (v, swa), (Z, idf) in steps:
+            e.predict(v, swa, w.QE, w.wb, w.dt)
+            e.update(Z, w.RE, idf, batch=True)
+        X, P = e.get_state()
+        assert e.factor_status() == 0
+        e.close()
+        return X, P
+
+    for defer in (0, 128):
+        X0, P0 = run(0, defer)
+        X1, P1 = run(1, defer)
+        assert np.array_equal(X0, X1) and np.array_equal(P0, P1), defer
