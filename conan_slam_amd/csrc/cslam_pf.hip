@@ -1017,6 +1017,7 @@ struct Pf : PfBase
         // (zero-copy -- the kernels reading the pinned slot over the host link -- was tried instead of this staged copy:
         // 13.7 k instead of 15.0 k steps/s)
         staged.clear();
+        // (a small kernel reading the pinned slot in place of this copy command: 19.6 k instead of 19.9 k steps/s)
         // (a second stream for this copy, double-buffered inputs and event hand-overs so that it runs under the previous
         // step's kernels was tried: 14.8 k instead of 16.7 k steps/s -- four more runtime calls per step cost more host
         // time than the 10 us of stream time they free)
