@@ -216,7 +216,7 @@ class DeviceInputs:
             Z, idf = w.observations(t)
             self.Zh[t] = Z.reshape(-1, order="F")
             self.Ih[t] = idf
-            self.phi[t] = w.true_pose_after(t)[2] if False else w._true_pose[2]
+            self.phi[t] = w._true_pose[2]  # (Workload.observations has integrated the true pose up to step t)
         self.dZ = torch.from_numpy(self.Zh).cuda()
         self.dI = torch.from_numpy(self.Ih).cuda()
         torch.cuda.synchronize()
@@ -334,6 +334,10 @@ def ekf_main(args):
     extras = (world == 1 and not args.no_extras and not args.sequential)
     n_bracket, n_call, n_drop = (64, 64, 48) if extras else (0, 0, 0)
     pre_cap = 8000 if (args.warmup < 400 and args.preheat_ms > 0) else 0  # input slots for the preheat loop
+    # short invocations (the driver's `--steps 20 --warmup 5`) are first run COLD -- W warm-up + K timed steps on a GPU
+    # that has just been handed to this process -- and reported as `cold_steps_per_sec`; then comes the preheat
+    n_cold = (args.warmup + args.steps) if (pre_cap and world == 1) else 0
+    pre_cap += n_cold
     total = pre_cap + args.warmup + args.steps
     w = Workload(N, args.obs, dtype, seed=rank)
     n, m, k = w.n, args.obs, 2 * args.obs
@@ -363,6 +367,18 @@ def ekf_main(args):
             dist.barrier()
 
     preheat_steps = 0
+    cold_rate = None
+    if n_cold:
+        for t in range(args.warmup):
+            step(t)
+        barrier()
+        c0 = time.perf_counter()
+        for t in range(args.warmup, n_cold):
+            step(t)
+        eng.flush()
+        eng.synchronize()
+        cold_rate = args.steps / (time.perf_counter() - c0)
+        preheat_steps = n_cold
     if pre_cap:
         t_end = time.perf_counter() + args.preheat_ms * 1e-3
         while preheat_steps < pre_cap and time.perf_counter() < t_end:
@@ -370,6 +386,7 @@ def ekf_main(args):
                 step(t)
             preheat_steps = min(pre_cap, preheat_steps + 100)
             eng.synchronize()
+        preheat_steps -= n_cold
     for t in range(pre_cap, pre_cap + args.warmup):
         step(t)
     barrier()
@@ -416,7 +433,12 @@ def ekf_main(args):
         t_next += n_bracket
         b_ms, b_cnt = st["downdate"]
         bracket = {"launch_us_mean": b_ms / max(b_cnt, 1) * 1e3, "launches": b_cnt}
-        if not dd_cnt:
+        if dd_cnt < 16 and b_cnt >= 16:
+            # a short timed region samples only a handful of launches (an event pair costs ~11 us of stream time, so
+            # not every launch of the timed region is bracketed): the roofline is then priced on the bracketed pass
+            # (every launch of 64 further steps), the in-region sample is kept beside it
+            bracket["timed_region_sample_us"] = dd_s * 1e6 if dd_s else None
+            bracket["timed_region_sample_launches"] = dd_cnt
             dd_s, dd_cnt = (b_ms / b_cnt) * 1e-3, b_cnt
     out = {
         "metric": "ekf_update_steps_per_sec",
@@ -426,6 +448,10 @@ def ekf_main(args):
         "steps": args.steps,
         "warmup": args.warmup,
         "preheat_steps": preheat_steps,
+        "cold_steps_per_sec": cold_rate,
+        "value_is": "asynchronous throughput: K steps enqueued back to back, inputs resident in HBM, nothing returned to the "
+                    "host inside the timed region; the per-call figure of SURVEY 8d (X returned every call) is "
+                    "per_call_steps_per_sec",
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
@@ -490,6 +516,7 @@ def ekf_main(args):
         out["per_call"] = dict(quantiles_ms(ts[8:]), note="wall time of predict+update with X returned to the host "
                                "after every call (median of the calls after 8 warm-ups); asynchronous mode, Z/idf in HBM",
                                steps_per_sec_at_median=1e3 / quantiles_ms(ts[8:])["median_ms"])
+        out["per_call_steps_per_sec"] = out["per_call"]["steps_per_sec_at_median"]  # SURVEY 8d's definition of the metric
         # what INTEGRATION.md's adapter does per call: sync mode (host-side eigen fallback armed), host Z / idf,
         # X read back after predict and after update (slam.h:841-847, 938-943 pass X by reference)
         eng.flush()
@@ -522,6 +549,8 @@ def ekf_main(args):
             # every control step is what keeps the reference's own filter healthy; factor_flags tells
             # whether it stayed so on this map
             out["reference_loop_ref_exact"] = reference_loop(args, torch, w, N, Q_REF_EXACT)
+    if extras:
+        out["ref_exact_healthy"] = ref_exact_healthy(args, torch, N, dtype)
     if world == 1 and not args.no_cpu_baseline:
         w.P0 = None
         out["cpu_baseline"] = cpu_baseline(N, args.obs, dtype, args.dtype, args.quirks, args.cpu_baseline_seconds)
@@ -533,6 +562,51 @@ def ekf_main(args):
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def ref_exact_healthy(args, torch, N, dtype):
+    """One timed number that runs the REFERENCE's own gain (REF_EXACT: lower-Cholesky factor slam.h:250-260, n-4 stripe
+    EKF.cpp:442-443) with healthy updates: on SURVEY 8d's strongly correlated P0 that gain turns P indefinite on the first
+    update and every later update is the reference's LLT-failure no-op, so this record uses the scenario
+    of tests/test_timed_path_gpu.py (b): weakly correlated P0 (U entries N(0, 0.1^2)) and observeHeading on every control
+    step as the reference's driver does (test/main.cpp:165-168).  Same kernels as the headline; factor_flags must be 0."""
+    from conan_slam_amd import EKF, Q_REF_EXACT
+    from conan_slam_amd.synth import Workload
+
+    n_w, n_t = 10, 100
+    m = args.obs
+    w = Workload(N, m, dtype, seed=0, corr=0.1)
+    eng = EKF(N, dtype=dtype, quirks=Q_REF_EXACT, sync_mode=False)
+    eng.set_state(w.X0, w.P0)
+    w.P0 = None
+    if args.defer > 0:
+        eng.set_deferred(args.defer)
+    inp = DeviceInputs(torch, w, n_w + n_t)
+
+    def step(t):
+        v, swa = inp.ctrl[t]
+        eng.predict(v, swa, w.QE, w.wb, w.dt)
+        eng.observe_heading(float(inp.phi[t]), True)
+        eng.update_device(inp.z(t), m, w.RE, inp.i(t), batch=True)
+
+    for t in range(n_w):
+        step(t)
+    eng.flush()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for t in range(n_w, n_w + n_t):
+        step(t)
+    eng.flush()
+    eng.synchronize()
+    el = time.perf_counter() - t0
+    rec = {"value": n_t / el, "unit": "update steps/s", "ms_per_step": el / n_t * 1e3, "steps": n_t,
+           "factor_flags": eng.factor_status(), "trace_P_end": eng.trace(), "gain_algebra": "ref_exact",
+           "deferred_columns": args.defer,
+           "note": "step = predict + observeHeading + batch update (m observations), REF_EXACT quirks, P0 = I + U U^T with U "
+                   "entries N(0, 0.1^2); the heading column joins the pending store, so a 128-column window holds one update "
+                   "(64 + 1 columns) and every update's P-GEMM runs with k = 65 or 66 (four chunks of 24)"}
+    eng.close()
+    return rec
 
 
 def reference_loop(args, torch, w, N, quirks):

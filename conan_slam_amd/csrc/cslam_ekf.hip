@@ -1401,7 +1401,10 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipMalloc(&dPred, 16 * sizeof(T)));
         }
-        if ((rc = ensure_w(std::max(k, kp_call_limit)))) // (may flush and move the store)
+        // the general gain kernels and ekf_pose_downdate_kernel write whole blocks of 8 columns of the slot: the slot starts
+        // at column kp (heading columns make kp any number), so kp + round_up(k, 8) must stay inside the region
+        const int k8w = round_up(k, 8);
+        if ((rc = ensure_w(std::max(k8w, kp_call_limit)))) // (may flush and move the store)
         {
             return rc;
         }
@@ -1412,7 +1415,7 @@ struct Ekf : EkfBase
         // sequential call's own columns, else the store (e.g. heading columns in immediate mode: applied together with
         // this update's panel by the flush below)
         const int window = std::min(wcap, defer_max > 0 ? defer_max : (kp_call_limit > 0 ? kp_call_limit : wcap));
-        if (!overlap && kp > 0 && kp + k > window)
+        if (!overlap && kp > 0 && (kp + k > window || kp + k8w > wcap))
         {
             if ((rc = flush())) // no room to keep them pending: apply them first
             {
@@ -1635,11 +1638,12 @@ struct Ekf : EkfBase
         // it needs as Ps[:,c] - Wp*Wp[c,:]^T.
         if (seq_defer)
         {
-            if ((rc = ensure_w(2 * m)))
+            // (every rank-2 slot is written as a block of 8 columns: the last one reaches column kp + 2m + 6)
+            if ((rc = ensure_w(2 * m + 8)))
             {
                 return rc;
             }
-            if (kp + 2 * m > wcap && (rc = flush()))
+            if (kp + 2 * m + 6 > wcap && (rc = flush()))
             {
                 return rc;
             }

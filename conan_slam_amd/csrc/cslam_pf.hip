@@ -9,7 +9,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types only: the library itself is bound with dlopen (see Rccl below)
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -90,12 +93,234 @@ inline Rccl* rccl()
         }                                                                                                            \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------
+// The communicator of the sharded resample.  Two back-ends behind one interface:
+//   RCCL      one process (rank) per GPU, collectives over xGMI -- production;
+//   loopback  `world` ranks that live in ONE process on ONE device, one host thread per rank (RCCL refuses the same device
+//             twice in a communicator, SURVEY 7 "hard parts"): all-reduce / all-gather / send-recv are device-to-device
+//             copies ordered by a host barrier.  It exists so that the multi-rank code paths of
+//             cslam_pf_resample_sharded (ranks > 0, the exchange plan, the receive ordering) can run under test on a
+//             one-GPU box; it is slow on purpose (every collective synchronises the calling rank's stream twice).
+// ------------------------------------------------------------------------------------------------
+constexpr int kLoopMaxWorld = 16;
+
+struct LoopPtrs
+{
+    const double* p[kLoopMaxWorld];
+};
+
+__global__ void comm_loop_sum_kernel(LoopPtrs ptrs, int world, double* __restrict__ out, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count)
+    {
+        double s = 0.0;
+        for (int r = 0; r < world; r++) // rank order: the same sum on every rank
+        {
+            s += ptrs.p[r][i];
+        }
+        out[i] = s;
+    }
+}
+
+struct LoopShared
+{
+    int                     world = 1;
+    int                     refs  = 0;
+    std::mutex              mu;
+    std::condition_variable cv;
+    int                     arrived = 0;
+    unsigned                gen     = 0;
+    bool                    broken  = false; // a rank gave up (error / timeout): every later barrier fails at once
+    std::vector<const void*> src;            // [rank] buffer registered for the collective in flight
+    struct P2P
+    {
+        const void* ptr   = nullptr;
+        size_t      bytes = 0;
+    };
+    std::vector<P2P> sends; // [from * world + to] of the group in flight
+
+    // all `world` ranks arrive, or false after `seconds` (a peer failed and never came)
+    bool barrier(double seconds = 60.0)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken)
+        {
+            return false;
+        }
+        const unsigned g = gen;
+        if (++arrived == world)
+        {
+            arrived = 0;
+            gen++;
+            cv.notify_all();
+            return true;
+        }
+        const bool ok = cv.wait_for(lk, std::chrono::duration<double>(seconds), [&] { return gen != g || broken; });
+        if (!ok || broken)
+        {
+            broken = true;
+            cv.notify_all();
+            return false;
+        }
+        return true;
+    }
+    void poison()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        broken = true;
+        cv.notify_all();
+    }
+};
+
 struct Comm
 {
-    ncclComm_t comm   = nullptr;
-    int        rank   = 0;
-    int        world  = 1;
-    int        device = 0;
+    ncclComm_t  comm   = nullptr; // RCCL back-end
+    LoopShared* loop   = nullptr; // loopback back-end
+    int         rank   = 0;
+    int         world  = 1;
+    int         device = 0;
+    bool        in_group = false;
+    struct Rv
+    {
+        void*  ptr;
+        size_t bytes;
+        int    peer;
+    };
+    std::vector<Rv> recvs; // loopback: receives of the open group
+
+    int loop_fail(const char* what)
+    {
+        loop->poison();
+        return ::cslam::fail(CSLAM_ERR_HIP, "loopback communicator: %s (rank %d of %d)", what, rank, world);
+    }
+
+    // recv[i] = sum over ranks of send[i], i < count doubles; identical on every rank
+    int all_reduce_sum_f64(const double* send, double* recv, int count, hipStream_t st)
+    {
+        if (!loop)
+        {
+            CSLAM_RCCL_TRY(rccl()->AllReduce(send, recv, (size_t)count, ncclDouble, ncclSum, comm, st));
+            return CSLAM_OK;
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(st)); // `send` is complete
+        loop->src[(size_t)rank] = send;
+        if (!loop->barrier())
+        {
+            return loop_fail("all-reduce: a peer never arrived");
+        }
+        LoopPtrs ptrs{};
+        for (int r = 0; r < world; r++)
+        {
+            ptrs.p[r] = static_cast<const double*>(loop->src[(size_t)r]);
+        }
+        hipLaunchKernelGGL(comm_loop_sum_kernel, dim3((count + 63) / 64), dim3(64), 0, st, ptrs, world, recv, count);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipStreamSynchronize(st)); // every peer's `send` has been read before anybody moves on
+        if (!loop->barrier())
+        {
+            return loop_fail("all-reduce: a peer never finished");
+        }
+        return CSLAM_OK;
+    }
+
+    // recv[r * bytes .. (r+1) * bytes) = rank r's send
+    int all_gather(const void* send, void* recv, size_t count, ncclDataType_t dt, size_t elt, hipStream_t st)
+    {
+        if (!loop)
+        {
+            CSLAM_RCCL_TRY(rccl()->AllGather(send, recv, count, dt, comm, st));
+            return CSLAM_OK;
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(st));
+        loop->src[(size_t)rank] = send;
+        if (!loop->barrier())
+        {
+            return loop_fail("all-gather: a peer never arrived");
+        }
+        const size_t bytes = count * elt;
+        for (int r = 0; r < world; r++)
+        {
+            CSLAM_HIP_TRY(hipMemcpyAsync(static_cast<char*>(recv) + (size_t)r * bytes, loop->src[(size_t)r], bytes,
+                                         hipMemcpyDeviceToDevice, st));
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(st));
+        if (!loop->barrier())
+        {
+            return loop_fail("all-gather: a peer never finished");
+        }
+        return CSLAM_OK;
+    }
+
+    int group_start()
+    {
+        in_group = true;
+        if (!loop)
+        {
+            CSLAM_RCCL_TRY(rccl()->GroupStart());
+            return CSLAM_OK;
+        }
+        recvs.clear();
+        for (int r = 0; r < world; r++)
+        {
+            loop->sends[(size_t)rank * world + r] = LoopShared::P2P{};
+        }
+        return CSLAM_OK;
+    }
+    int send(const void* buf, size_t count, ncclDataType_t dt, size_t elt, int peer, hipStream_t st)
+    {
+        if (!loop)
+        {
+            CSLAM_RCCL_TRY(rccl()->Send(buf, count, dt, peer, comm, st));
+            return CSLAM_OK;
+        }
+        loop->sends[(size_t)rank * world + peer] = LoopShared::P2P{buf, count * elt};
+        return CSLAM_OK;
+    }
+    int recv(void* buf, size_t count, ncclDataType_t dt, size_t elt, int peer, hipStream_t st)
+    {
+        if (!loop)
+        {
+            CSLAM_RCCL_TRY(rccl()->Recv(buf, count, dt, peer, comm, st));
+            return CSLAM_OK;
+        }
+        recvs.push_back(Rv{buf, count * elt, peer});
+        return CSLAM_OK;
+    }
+    // closes the group on every path (a group left open would swallow the next collective)
+    int group_end(hipStream_t st)
+    {
+        if (!in_group)
+        {
+            return CSLAM_OK;
+        }
+        in_group = false;
+        if (!loop)
+        {
+            CSLAM_RCCL_TRY(rccl()->GroupEnd());
+            return CSLAM_OK;
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(st)); // the send buffers are packed
+        if (!loop->barrier())
+        {
+            return loop_fail("send/recv: a peer never arrived");
+        }
+        for (const Rv& rv : recvs)
+        {
+            const LoopShared::P2P& sp = loop->sends[(size_t)rv.peer * world + rank];
+            if (sp.ptr == nullptr || sp.bytes != rv.bytes)
+            {
+                return loop_fail("send/recv: a receive has no matching send of the same size");
+            }
+            CSLAM_HIP_TRY(hipMemcpyAsync(rv.ptr, sp.ptr, rv.bytes, hipMemcpyDeviceToDevice, st));
+        }
+        CSLAM_HIP_TRY(hipStreamSynchronize(st));
+        if (!loop->barrier()) // nobody reuses a send buffer before its receiver has copied it
+        {
+            return loop_fail("send/recv: a peer never finished");
+        }
+        return CSLAM_OK;
+    }
 };
 
 struct PfBase
@@ -127,6 +352,7 @@ struct PfBase
     virtual int gather_local(const int* keep, double w_new)                                   = 0;
     virtual int resample_local(const void* select, double n_eff, int status, double* neff, int* did) = 0;
     virtual int resample_sharded(Comm* c, const void* select, double n_eff, int status, double* neff, int* did) = 0;
+    virtual int debug_last_exchange(int* counts, int* send_idx, int cap, int* n_send)                = 0;
     virtual int observation_step(double v, double swa, const void* Q, double wb, double dt, const void* Z, int m,
                                  const int* idf, const void* R, const void* normals, const void* select, double n_eff,
                                  int status) = 0;
@@ -791,38 +1017,38 @@ struct Pf : PfBase
     T*      dRecvBuf = nullptr;
     int     sh_world = 0;
     int     sh_nf    = -1;
-    int resample_sharded(Comm* c, const void* select, double n_eff, int status, double* neff, int* did) override
+    std::vector<int> last_counts; // 2 * world record counts of the last exchange (send per destination, receive per source)
+    int              last_n_send = 0;
+
+    template <typename P>
+    static void refree(P*& p)
     {
-        Rccl* R = rccl();
-        if (!R)
-        {
-            return fail(CSLAM_ERR_HIP, "pf_resample_sharded: librccl could not be loaded");
-        }
-        if (!c || !select)
-        {
-            return fail(CSLAM_ERR_BAD_ARG, "pf_resample_sharded: null communicator or select");
-        }
-        const int world = c->world, rank = c->rank, L = np, N = np * world;
-        int rc = use_device();
-        if (rc)
-        {
-            return rc;
-        }
-        const ncclDataType_t dt = (sizeof(T) == 4) ? ncclFloat : ncclDouble;
+        (void)hipFree(p);
+        p = nullptr;
+    }
+
+    // buffers of the sharded resample: everything that can fail is allocated BEFORE the first collective, so that a rank
+    // never leaves its peers waiting inside one because a local allocation failed
+    int ensure_sharded_buffers(int world)
+    {
+        const int N = np * world;
         if (sh_world != world)
         {
             CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-            (void)hipFree(dSumsG);
-            (void)hipFree(dWall);
-            (void)hipFree(dSelG);
-            (void)hipFree(dCumG);
-            (void)hipFree(dKeepG);
-            (void)hipFree(dSendIdx);
-            (void)hipFree(dCounts);
+            refree(dSumsG);
+            refree(dWall);
+            refree(dSelG);
+            refree(dCumG);
+            refree(dKeepG);
+            refree(dSendIdx);
+            refree(dCounts);
             if (hCounts)
             {
                 (void)hipHostFree(hCounts);
+                hCounts = nullptr;
             }
+            sh_world = 0;
+            sh_nf    = -1;
             CSLAM_HIP_TRY(hipMalloc(&dSumsG, 2 * sizeof(double)));
             CSLAM_HIP_TRY(hipMalloc(&dWall, (size_t)N * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dSelG, (size_t)N * sizeof(T)));
@@ -832,12 +1058,57 @@ struct Pf : PfBase
             CSLAM_HIP_TRY(hipMalloc(&dCounts, (size_t)2 * world * sizeof(int)));
             CSLAM_HIP_TRY(hipHostMalloc(&hCounts, ((size_t)2 * world + 4) * sizeof(double), hipHostMallocDefault));
             sh_world = world;
-            sh_nf    = -1;
+        }
+        if (sh_nf != nf)
+        {
+            const size_t rec = (size_t)(13 + 6 * nf);
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            refree(dSendBuf);
+            refree(dRecvBuf);
+            sh_nf = -1;
+            CSLAM_HIP_TRY(hipMalloc(&dSendBuf, (size_t)N * rec * sizeof(T))); // worst case: every slot keeps a particle of this rank
+            CSLAM_HIP_TRY(hipMalloc(&dRecvBuf, (size_t)np * rec * sizeof(T)));
+            sh_nf = nf;
+        }
+        return CSLAM_OK;
+    }
+
+    int resample_sharded(Comm* c, const void* select, double n_eff, int status, double* neff, int* did) override
+    {
+        if (!c || !select)
+        {
+            return fail(CSLAM_ERR_BAD_ARG, "pf_resample_sharded: null communicator or select");
+        }
+        if (!c->loop && !rccl())
+        {
+            return fail(CSLAM_ERR_HIP, "pf_resample_sharded: librccl could not be loaded");
+        }
+        const int world = c->world, rank = c->rank, L = np, N = np * world;
+        int rc = use_device();
+        if (rc || (rc = ensure_sharded_buffers(world)))
+        {
+            return rc;
+        }
+        const ncclDataType_t dt = (sizeof(T) == 4) ? ncclFloat : ncclDouble;
+        // the strata positions go to the device up front as well (staging can fail; the copy is cheap when unused)
+        char* slot = nullptr;
+        if ((rc = stage_slot_for((size_t)N * sizeof(T), &slot)))
+        {
+            return rc;
+        }
+        std::memcpy(slot, select, (size_t)N * sizeof(T));
+        CSLAM_HIP_TRY(hipMemcpyAsync(dSelG, slot, (size_t)N * sizeof(T), hipMemcpyHostToDevice, stream));
+        if ((rc = stage_commit()))
+        {
+            return rc;
         }
         // 1. global weight sums
         hipLaunchKernelGGL(pf_weight_sums_kernel<T>, dim3(1), dim3(256), 0, stream, dW, np, dSums);
         CSLAM_HIP_TRY(hipGetLastError());
-        CSLAM_RCCL_TRY(R->AllReduce(dSums, dSumsG, 2, ncclDouble, ncclSum, c->comm, stream));
+        if ((rc = c->all_reduce_sum_f64(dSums, dSumsG, 2, stream)))
+        {
+            return rc;
+        }
         double* hs = reinterpret_cast<double*>(hCounts); // (pinned; the counts use it later)
         CSLAM_HIP_TRY(hipMemcpyAsync(hs, dSumsG, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
@@ -856,20 +1127,14 @@ struct Pf : PfBase
         {
             *did = go ? 1 : 0;
         }
+        last_counts.assign((size_t)2 * world, 0);
+        last_n_send = 0;
         if (!go)
         {
             return CSLAM_OK;
         }
         // 3. every rank plans the same keep[] from the gathered weights and the shared strata
-        CSLAM_RCCL_TRY(R->AllGather(dW, dWall, (size_t)L, dt, c->comm, stream));
-        char* slot = nullptr;
-        if ((rc = stage_slot_for((size_t)N * sizeof(T), &slot)))
-        {
-            return rc;
-        }
-        std::memcpy(slot, select, (size_t)N * sizeof(T));
-        CSLAM_HIP_TRY(hipMemcpyAsync(dSelG, slot, (size_t)N * sizeof(T), hipMemcpyHostToDevice, stream));
-        if ((rc = stage_commit()))
+        if ((rc = c->all_gather(dW, dWall, (size_t)L, dt, sizeof(T), stream)))
         {
             return rc;
         }
@@ -888,63 +1153,97 @@ struct Pf : PfBase
             n_send += hc[r];
             n_recv += hc[world + r];
         }
-        if (n_recv != L)
+        last_counts.assign(hc, hc + 2 * world);
+        last_n_send = n_send;
+        // (every rank derives the plan from the same gathered weights, so these checks fail on all ranks or on none)
+        if (n_recv != L || hc[rank] != hc[world + rank])
         {
-            return fail(CSLAM_ERR_HIP, "pf_resample_sharded: exchange plan fills %d of %d slots", n_recv, L);
+            return fail(CSLAM_ERR_HIP, "pf_resample_sharded: inconsistent exchange plan (%d of %d slots filled, self %d / %d)",
+                        n_recv, L, hc[rank], hc[world + rank]);
         }
         const size_t rec = (size_t)(13 + 6 * nf);
-        if (sh_nf != nf)
-        {
-            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-            (void)hipFree(dSendBuf);
-            (void)hipFree(dRecvBuf);
-            dSendBuf = dRecvBuf = nullptr;
-            CSLAM_HIP_TRY(hipMalloc(&dSendBuf, (size_t)N * rec * sizeof(T))); // worst case: every slot keeps a particle of this rank
-            CSLAM_HIP_TRY(hipMalloc(&dRecvBuf, (size_t)L * rec * sizeof(T)));
-            sh_nf = nf;
-        }
         // 4. records out of the store (before any slot is overwritten), exchange, records into the slots in order
         if (n_send > 0)
         {
             hipLaunchKernelGGL(pf_pack_kernel<T>, dim3(n_send), dim3(256), 0, stream, store(), dSendIdx, n_send, dSendBuf);
             CSLAM_HIP_TRY(hipGetLastError());
         }
-        CSLAM_RCCL_TRY(R->GroupStart());
+        // the records that stay on this rank: a device copy, outside the group
+        {
+            size_t soff = 0, roff = 0;
+            for (int r = 0; r < rank; r++)
+            {
+                soff += (size_t)hc[r];
+                roff += (size_t)hc[world + r];
+            }
+            if (hc[rank] > 0)
+            {
+                CSLAM_HIP_TRY(hipMemcpyAsync(dRecvBuf + roff * rec, dSendBuf + soff * rec, (size_t)hc[rank] * rec * sizeof(T),
+                                             hipMemcpyDeviceToDevice, stream));
+            }
+        }
+        if ((rc = c->group_start()))
+        {
+            return rc;
+        }
         size_t soff = 0, roff = 0;
-        for (int r = 0; r < world; r++)
+        for (int r = 0; r < world && rc == CSLAM_OK; r++)
         {
             const size_t sc = (size_t)hc[r], rcv = (size_t)hc[world + r];
-            if (r == rank)
-            {
-                if (sc != rcv)
-                {
-                    (void)R->GroupEnd();
-                    return fail(CSLAM_ERR_HIP, "pf_resample_sharded: self counts differ (%zu / %zu)", sc, rcv);
-                }
-                if (sc > 0)
-                {
-                    CSLAM_HIP_TRY(hipMemcpyAsync(dRecvBuf + roff * rec, dSendBuf + soff * rec, sc * rec * sizeof(T),
-                                                 hipMemcpyDeviceToDevice, stream));
-                }
-            }
-            else
+            if (r != rank)
             {
                 if (sc > 0)
                 {
-                    CSLAM_RCCL_TRY(R->Send(dSendBuf + soff * rec, sc * rec, dt, r, c->comm, stream));
+                    rc = c->send(dSendBuf + soff * rec, sc * rec, dt, sizeof(T), r, stream);
                 }
-                if (rcv > 0)
+                if (rcv > 0 && rc == CSLAM_OK)
                 {
-                    CSLAM_RCCL_TRY(R->Recv(dRecvBuf + roff * rec, rcv * rec, dt, r, c->comm, stream));
+                    rc = c->recv(dRecvBuf + roff * rec, rcv * rec, dt, sizeof(T), r, stream);
                 }
             }
             soff += sc;
             roff += rcv;
         }
-        CSLAM_RCCL_TRY(R->GroupEnd());
+        const int rc_end = c->group_end(stream); // (closed on the failure path too)
+        if (rc || rc_end)
+        {
+            return rc ? rc : rc_end;
+        }
         hipLaunchKernelGGL(pf_unpack_kernel<T>, dim3(L), dim3(256), 0, stream, store(), (const int*)nullptr, L, dRecvBuf);
         CSLAM_HIP_TRY(hipGetLastError());
         return set_uniform_weight(1.0 / (double)N); // PF.cpp:495-499
+    }
+
+    // test introspection: the record counts (2 * world) and the send list of the last sharded resample
+    int debug_last_exchange(int* counts, int* send_idx, int cap, int* n_send) override
+    {
+        if (n_send)
+        {
+            *n_send = last_n_send;
+        }
+        if (counts)
+        {
+            for (size_t i = 0; i < last_counts.size(); i++)
+            {
+                counts[i] = last_counts[i];
+            }
+        }
+        if (send_idx && last_n_send > 0)
+        {
+            if (cap < last_n_send)
+            {
+                return fail(CSLAM_ERR_BAD_ARG, "debug_last_exchange: capacity %d < %d", cap, last_n_send);
+            }
+            int rc = use_device();
+            if (rc)
+            {
+                return rc;
+            }
+            CSLAM_HIP_TRY(hipMemcpyAsync(send_idx, dSendIdx, (size_t)last_n_send * sizeof(int), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            stage_inflight = 0;
+        }
+        return CSLAM_OK;
     }
 
     // plan (sums, normalise, Neff, decision, keep[]) -> gather -> copy back + w = 1/N, the last two gated by a device flag
@@ -1442,6 +1741,51 @@ int cslam_comm_create(const void* id_bytes, int rank, int world, int device, csl
     return CSLAM_OK;
 }
 
+int cslam_comm_create_loopback(int world, int device, cslam_comm_t* out)
+{
+    if (!out || world < 1 || world > kLoopMaxWorld)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "comm_create_loopback: world must be 1..%d", kLoopMaxWorld);
+    }
+    for (int r = 0; r < world; r++)
+    {
+        out[r] = nullptr;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess)
+    {
+        device = 0;
+    }
+    LoopShared* sh = new (std::nothrow) LoopShared();
+    if (!sh)
+    {
+        return fail(CSLAM_ERR_ALLOC, "comm_create_loopback: out of host memory");
+    }
+    sh->world = world;
+    sh->refs  = world;
+    sh->src.assign((size_t)world, nullptr);
+    sh->sends.assign((size_t)world * world, LoopShared::P2P{});
+    for (int r = 0; r < world; r++)
+    {
+        Comm* c = new (std::nothrow) Comm();
+        if (!c)
+        {
+            for (int q = 0; q < r; q++)
+            {
+                delete reinterpret_cast<Comm*>(out[q]);
+                out[q] = nullptr;
+            }
+            delete sh;
+            return fail(CSLAM_ERR_ALLOC, "comm_create_loopback: out of host memory");
+        }
+        c->loop   = sh;
+        c->rank   = r;
+        c->world  = world;
+        c->device = device;
+        out[r]    = reinterpret_cast<cslam_comm_t>(c);
+    }
+    return CSLAM_OK;
+}
+
 int cslam_comm_destroy(cslam_comm_t c)
 {
     if (!c)
@@ -1449,12 +1793,48 @@ int cslam_comm_destroy(cslam_comm_t c)
         return CSLAM_OK;
     }
     Comm* cc = reinterpret_cast<Comm*>(c);
-    if (Rccl* R = rccl())
+    if (cc->loop)
+    {
+        bool last = false;
+        {
+            std::lock_guard<std::mutex> lk(cc->loop->mu);
+            last = (--cc->loop->refs == 0);
+        }
+        if (last)
+        {
+            delete cc->loop;
+        }
+    }
+    else if (Rccl* R = rccl())
     {
         (void)R->CommDestroy(cc->comm);
     }
     delete cc;
     return CSLAM_OK;
+}
+
+int cslam_comm_info(cslam_comm_t c, int* rank, int* world)
+{
+    if (!c)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "comm_info: null communicator");
+    }
+    const Comm* cc = reinterpret_cast<const Comm*>(c);
+    if (rank)
+    {
+        *rank = cc->rank;
+    }
+    if (world)
+    {
+        *world = cc->world;
+    }
+    return CSLAM_OK;
+}
+
+int cslam_pf_debug_last_exchange(cslam_pf_t h, int* counts, int* send_idx, int capacity, int* n_send)
+{
+    CSLAM_NEED(h);
+    return B(h)->debug_last_exchange(counts, send_idx, capacity, n_send);
 }
 
 int cslam_pf_resample_sharded(cslam_pf_t h, cslam_comm_t comm, const void* select, double n_effective,

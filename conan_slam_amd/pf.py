@@ -161,6 +161,27 @@ class RcclComm:
             self._h = C.c_void_p(None)
 
 
+class LoopbackComm:
+    """One rank of an in-process loopback communicator (cslam_comm_create_loopback): `world` ranks on ONE device, each
+    driven from its own host thread.  Lets the multi-rank paths of cslam_pf_resample_sharded run on a one-GPU box."""
+
+    def __init__(self, handle, rank: int, world: int, owner):
+        self._h, self.rank, self.world, self._owner = handle, rank, world, owner
+
+    @staticmethod
+    def create(world: int, device: int = -1):
+        L = _capi.lib()
+        arr = (C.c_void_p * world)()
+        check(L.cslam_comm_create_loopback(C.c_int(world), C.c_int(device), arr))
+        owner = {"L": L, "open": world}
+        return [LoopbackComm(C.c_void_p(arr[r]), r, world, owner) for r in range(world)]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._owner["L"].cslam_comm_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+
 # ------------------------------------------------------------------------------------------------
 # the shard on the GPU
 # ------------------------------------------------------------------------------------------------
@@ -299,6 +320,18 @@ class ParticleShard:
         check(self._L.cslam_pf_resample_sharded(self._h, comm._h, _vp(select), C.c_double(float(n_effective)),
                                                 C.c_int(1 if resample_status else 0), C.byref(neff), C.byref(did)))
         return float(neff.value), bool(did.value)
+
+    def debug_last_exchange(self, world: int):
+        """(send counts per destination, receive counts per source, local send indices) of the last sharded resample."""
+        counts = (C.c_int * (2 * world))()
+        n_send = C.c_int(0)
+        check(self._L.cslam_pf_debug_last_exchange(self._h, counts, None, C.c_int(0), C.byref(n_send)))
+        idx = np.zeros(max(n_send.value, 1), dtype=np.int32)
+        if n_send.value:
+            check(self._L.cslam_pf_debug_last_exchange(self._h, None, idx.ctypes.data_as(C.c_void_p), C.c_int(idx.shape[0]),
+                                                       C.byref(n_send)))
+        c = list(counts)
+        return c[:world], c[world:], idx[: n_send.value]
 
     def observation_step(self, v, swa, Q, wb, dt, Z, idf, R, normals, select, n_effective: float, resample_status: bool):
         """predict + sampleProposal + featureUpdate + resampleParticles for a shard that holds every particle, in one

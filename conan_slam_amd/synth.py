@@ -55,7 +55,8 @@ def noise_matrices(dtype=np.float32):
 class Workload:
     """A synthetic map + initial filter state + a stream of (controls, observations) per step."""
 
-    def __init__(self, n_landmarks: int, m_obs: int, dtype=np.float32, seed: int = 0, build_p: bool = True):
+    def __init__(self, n_landmarks: int, m_obs: int, dtype=np.float32, seed: int = 0, build_p: bool = True,
+                 corr: float = 0.5):
         self.N = int(n_landmarks)
         self.m = int(m_obs)
         self.n = 3 + 2 * self.N
@@ -71,7 +72,10 @@ class Workload:
         X0[3::2] = self.LM[0] + normal(s + 2, 2 * idx)
         X0[4::2] = self.LM[1] + normal(s + 2, 2 * idx + np.uint64(1))
         self.X0 = X0.astype(self.dtype)
-        self.U = (0.5 * normal(s + 3, np.arange(n * 8, dtype=np.uint64))).reshape(n, 8).astype(self.dtype)
+        # corr: standard deviation of U's entries (0.5 = SURVEY 8d's strongly correlated P0; <= 0.1 gives the weakly
+        # correlated P0 on which the reference's own lower-Cholesky gain stays healthy, see tests/test_timed_path_gpu.py)
+        self.corr = float(corr)
+        self.U = (self.corr * normal(s + 3, np.arange(n * 8, dtype=np.uint64))).reshape(n, 8).astype(self.dtype)
         self.U[0:3, :] *= self.dtype.type(0.1)  # pose block 1e-2, pose<->map cross terms 1e-1
         self.P0 = self.make_p0() if build_p else None
         self.Q, self.R, self.QE, self.RE = noise_matrices(self.dtype)

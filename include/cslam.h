@@ -137,8 +137,7 @@ int cslam_ekf_associate(cslam_ekf_t h, const void* Z, int m, const void* R, doub
  * results are the reference's up to rounding.  0 (default) applies each update's downdate at once.  The
  * sequential form update(batch = 0) always defers its m rank-2 downdates to one pass at the end of the call
  * (SURVEY.md 8f rank 2).  get_state / trace / associate / flush apply whatever is pending.
- * The default f32 engine is PIPELINED (two streams): the W1 panel of the last update is always pending and its P-GEMM
- * runs on the second stream underneath the next update's factor / gain chain; set_deferred widens that window. */
+ * The shipped engine is single-stream and applies every batch update's P-GEMM at once unless a window is set here. */
 int cslam_ekf_set_deferred(cslam_ekf_t h, int max_pending_columns);
 int cslam_ekf_flush(cslam_ekf_t h);
 
@@ -269,8 +268,21 @@ typedef struct cslam_comm* cslam_comm_t;
 int cslam_comm_unique_id(void* id_bytes);
 int cslam_comm_create(const void* id_bytes, int rank, int world, int device, cslam_comm_t* out);
 int cslam_comm_destroy(cslam_comm_t c);
+int cslam_comm_info(cslam_comm_t c, int* rank, int* world); /* either pointer may be NULL */
+/* A LOOPBACK communicator: `world` (<= 16) ranks inside ONE process on ONE device, out[0..world) their handles.  RCCL
+ * refuses the same device twice in one communicator, so this is how the multi-rank paths of cslam_pf_resample_sharded
+ * (ranks > 0, the exchange plan, the receive ordering by source rank) run on a one-GPU box: all-reduce, all-gather and
+ * the grouped send/recv become device-to-device copies ordered by a host barrier.  Every rank's
+ * cslam_pf_resample_sharded must be called from its OWN host thread (the ranks meet inside the call, as processes do
+ * over RCCL); a rank that fails or does not arrive within 60 s breaks the communicator for all.  For tests and for
+ * sharding one GPU's particle set by hand -- not a fast path. */
+int cslam_comm_create_loopback(int world, int device, cslam_comm_t* out);
 int cslam_pf_resample_sharded(cslam_pf_t h, cslam_comm_t comm, const void* select, double n_effective,
                               int resample_status, double* neff, int* resampled);
+/* Introspection for tests: the exchange plan of the LAST cslam_pf_resample_sharded on this handle.  counts: 2 * world
+ * ints -- records sent to each destination rank, then records received from each source rank (all 0 when it did not
+ * resample); send_idx: the local source indices in send order (capacity >= *n_send).  Any pointer may be NULL. */
+int cslam_pf_debug_last_exchange(cslam_pf_t h, int* counts, int* send_idx, int capacity, int* n_send);
 /* download one particle (host buffers; any may be NULL): w (1), Xv (3), Pv (9), XF (2*nf), PF (4*nf) */
 int cslam_pf_get_particle(cslam_pf_t h, int index, void* w, void* Xv, void* Pv, void* XF, void* PF);
 /* upload one particle with nf features (nf must equal the current feature count, or set it when the

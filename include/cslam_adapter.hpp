@@ -284,9 +284,20 @@ class HipPF : public PF
     /// the strata positions of PF.cpp:557 (stratifiedRandom): supplied by the caller so that runs are reproducible
     /// (the reference seeds from the clock, slam.h:587-594); when a communicator is set, `select` has one entry per
     /// particle of the WHOLE set (numParticles x ranks) and must be identical on every rank
+    /// The reference draws fresh strata on every call (stratifiedRandom, PF.cpp:557): so must the caller -- the strata
+    /// are consumed by the next resampleParticles and have to be set again before the one after.
     void setStrata(const Eigen::VectorXf& select) { select_ = select; }
     /// shard the particle set over ranks: resampleParticles then runs the three collectives of SURVEY 8e over RCCL
-    void setCommunicator(cslam_comm_t comm) { comm_ = comm; }
+    void setCommunicator(cslam_comm_t comm)
+    {
+        comm_  = comm;
+        world_ = 1;
+        if (comm != nullptr)
+        {
+            int rank = 0;
+            report(cslam_comm_info(comm, &rank, &world_), "HipPF::setCommunicator");
+        }
+    }
 
     /// slam.h:871-872, PF.cpp:473-500 -- on the particle set held in HBM.  `particles` is not touched: call download()
     /// when the host copy is needed.
@@ -294,6 +305,15 @@ class HipPF : public PF
     {
         double neff      = 0.0;
         int    resampled = 0;
+        // the engine reads numParticles x ranks strata positions from this pointer: refuse anything else, as loudly as
+        // the reference's catch blocks do (PF.cpp:215-218), instead of reading past the caller's vector
+        if (select_.rows() != static_cast<long>(np_) * world_)
+        {
+            std::cout << "HipPF::resampleParticles: setStrata() must supply " << static_cast<long>(np_) * world_
+                      << " strata positions before every resample (got " << select_.rows() << ")"
+                      << "\t" << "resampleParticles" << std::endl;
+            return;
+        }
         if (comm_ != nullptr)
         {
             report(cslam_pf_resample_sharded(h_, comm_, select_.data(), numEffective, resampleStatus ? 1 : 0, &neff,
@@ -307,6 +327,7 @@ class HipPF : public PF
         }
         lastNeff_      = static_cast<float>(neff);
         lastResampled_ = resampled != 0;
+        select_.resize(0); // consumed: the next resample needs its own strata
     }
     float lastNeff() const { return lastNeff_; }
     bool  lastResampled() const { return lastResampled_; }
@@ -314,6 +335,7 @@ class HipPF : public PF
   private:
     cslam_pf_t      h_    = nullptr;
     cslam_comm_t    comm_ = nullptr;
+    int             world_ = 1;
     int             np_   = 0;
     Eigen::VectorXf select_;
     float           lastNeff_      = 0.f;

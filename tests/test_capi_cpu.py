@@ -59,6 +59,13 @@ def test_adapter_header_compiles_and_links_against_the_library(tmp_path):
     r = subprocess.run([gxx, obj, "-L" + libdir, "-lcslam_hip", "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib",
                         "-Wl,--allow-shlib-undefined", "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    # the replay driver that tests/test_adapter_gpu.py builds and RUNS on the GPU box: same compile + link check here
+    rsrc = os.path.join(ROOT, "tests", "adapter", "adapter_replay.cpp")
+    rexe = str(tmp_path / "adapter_replay")
+    r = subprocess.run([gxx, "-std=c++17", "-Wall", "-Werror"] + inc + [rsrc, "-L" + libdir, "-lcslam_hip", "-L/opt/rocm/lib",
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", rexe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
     # without the stand-in and without Eigen the header must compile to nothing (it is guarded by __has_include)
     empty = tmp_path / "empty.cpp"
     empty.write_text('#include "cslam_adapter.hpp"\nint main() { return 0; }\n')

@@ -677,6 +677,37 @@ def test_reference_loop_cadence(gpu_required, dtype, quirks):
     eng.close()
 
 
+@pytest.mark.parametrize("m", [60, 61])
+def test_pending_store_window_with_heading_columns_f64(gpu_required, m):
+    """Heading observations append single pending columns, so an update's W1 slot may start at any column of the pending
+    store, while the general gain kernel and ekf_pose_downdate_kernel (f64 beyond k = 64) write whole blocks of 8
+    columns.  6 heading columns, then a batch of m = 61 (k = 122, round_up = 128) in the SECOND region of the 128-column
+    store: kp + k fits, kp + round_up(k, 8) does not -- the engine must apply the pending columns first instead of
+    writing past the store.  Against the f64 oracle."""
+    dtype, N = np.float64, 90
+    eng, orc, _ = _pair(N, dtype, TEXTBOOK, seed=77, extra=0, corr=0.1)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    rng = np.random.default_rng(m)
+    idf0 = (rng.permutation(N)[:4] + 1).astype(np.int32)
+    Z0 = make_obs(orc.x(), idf0, dtype, seed=5)
+    for s in (eng, orc):
+        s.update(Z0, R, idf0, True)          # immediate mode: its flush moves the pending store to region 1
+    for step in range(6):
+        for s in (eng, orc):
+            s.predict(83.33, 0.01 * step, Q, 73.0, 0.01)
+            s.observe_heading(0.3 + 1e-3 * step, True)
+    idf = (rng.permutation(N)[:m] + 1).astype(np.int32)
+    Z = make_obs(orc.x(), idf, dtype, seed=6)
+    for s in (eng, orc):
+        s.update(Z, R, idf, True)
+    X, P = eng.get_state()
+    assert eng.factor_status() == 0
+    assert_close("X", X, orc.x(), 1e-11)
+    assert_close("P", P, orc.p(), 1e-9)
+    eng.close()
+
+
 def test_pipelined_and_single_stream_engines_agree(gpu_required, monkeypatch):
     """The two-stream pipelined engine (P-GEMM of update t under the chain of update t+1) against the single-stream
     immediate engine on the same inputs at N = 1000: same answers up to the rounding of the pending-panel correction."""

@@ -303,6 +303,124 @@ def test_sharded_resample_behind_the_c_abi_world_of_one(gpu_required, dtype):
     _capi.check(L.cslam_comm_destroy(comm))
 
 
+def _run_ranks(fns, timeout=180.0):
+    """One host thread per rank (the ranks meet inside the call, as processes do over RCCL); re-raises a rank's error."""
+    import threading
+
+    out, err = [None] * len(fns), [None] * len(fns)
+
+    def body(r):
+        try:
+            out[r] = fns[r]()
+        except BaseException as e:  # noqa: BLE001 -- carried to the test thread
+            err[r] = e
+
+    th = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(len(fns))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout)
+    assert not any(t.is_alive() for t in th), "a rank hung inside the sharded resample"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("world,npart,nf,skew", [(2, 64, 3, "mild"), (4, 96, 5, "one_rank"), (8, 128, 2, "one_particle"),
+                                                  (8, 512, 1000, "mild"), (2, 96, 4, "none")])
+def test_sharded_resample_loopback_world_gt_1(gpu_required, world, npart, nf, skew):
+    """cslam_pf_resample_sharded with MORE than one rank (PF.cpp:473-500, 546-577 over block-partitioned particles):
+    `world` shards on one device behind the in-process loopback communicator (cslam_comm_create_loopback), one host
+    thread per rank.  The ranks > 0 paths -- pf_exchange_plan_kernel for rank > 0, the grouped send / recv, the receive
+    ordering by source rank -- must leave the concatenated shards bit-equal to cslam_pf_resample_local on the whole set
+    and to the oracle's keep[]; the device-side plan must equal conan_slam_amd/pf.py::plan_exchange for every rank.
+    512 x 1000 is BASELINE configs[3]'s particle set over 8 ranks."""
+    from conan_slam_amd.pf import LoopbackComm, SingleComm, plan_exchange, resample_particles, stratified_random
+
+    dtype = np.float32
+    L = npart // world
+    parts = _random_particles(npart, nf, dtype, seed=1000 + world)
+    rng = np.random.default_rng(7 * world + npart)
+    if skew == "mild":
+        w = rng.uniform(0.0, 1.0, npart) ** 5
+    elif skew == "one_rank":              # almost all the weight on rank 2's particles: everybody receives from it
+        w = np.full(npart, 1e-6)
+        w[2 * L:3 * L] = rng.uniform(0.5, 1.0, L)
+    elif skew == "one_particle":          # one survivor: every slot of every rank is a copy of it
+        w = np.full(npart, 1e-9)
+        w[npart - 3] = 1.0
+    else:                                 # uniform weights: Neff = N, no resample (weights only normalised)
+        w = np.full(npart, 0.37)
+    for p, wi in zip(parts, w):
+        p[0] = dtype(wi)
+    whole = _shard_from(parts, nf, dtype)
+    shards = [_shard_from(parts[r * L:(r + 1) * L], nf, dtype) for r in range(world)]
+    comms = LoopbackComm.create(world)
+    select = stratified_random(npart, rng.uniform(size=npart), dtype)
+    nmin = int(0.75 * npart)
+    res = _run_ranks([(lambda r=r: shards[r].resample_sharded(comms[r], select, nmin, True)) for r in range(world)])
+    ref = resample_particles(whole, SingleComm(), nmin, True, select=select)
+    o = Oracle(dtype)
+    wref = np.array([p[0] for p in parts], dtype=dtype)
+    neff_o, did_o, keep = o.pf_normalize_resample(wref, nmin, True, select)
+    expect = skew != "none"
+    assert ref[1] == did_o == expect
+    for r in range(world):
+        assert res[r][1] == expect and abs(res[r][0] - ref[0]) <= 1e-9 * abs(ref[0]), (r, res[r], ref)
+    # particles: shard r slot i == whole slot r*L + i == original particle keep[r*L + i], bit for bit
+    step = 1 if npart * nf <= 20000 else 3
+    for g in range(0, npart, step):
+        got = shards[g // L].get_particle(g % L)
+        ws = whole.get_particle(g)
+        src = parts[keep[g]] if expect else parts[g]
+        for a, b in zip(got[1:], ws[1:]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), ("vs whole set", g)
+        for a, b in zip(got[1:], src[1:]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), ("vs oracle keep", g, int(keep[g]))
+    wall = np.concatenate([sh.get_weights() for sh in shards])
+    if expect:
+        assert np.array_equal(wall, whole.get_weights()) and np.all(wall == dtype(1.0 / npart))
+    else:
+        # no resample: w / ws only; the all-reduce adds the per-rank partial sums, the whole set adds in one sweep
+        assert np.allclose(wall, whole.get_weights(), rtol=2e-7, atol=0)
+    # the exchange plan of every rank against the host planner
+    for r in range(world):
+        send_c, recv_c, send_idx = shards[r].debug_last_exchange(world)
+        if expect:
+            src_l, sc, _, rc_ = plan_exchange(np.asarray(keep), r, world, L)
+            assert send_c == sc and recv_c == rc_, (r, send_c, sc, recv_c, rc_)
+            assert np.array_equal(send_idx, src_l), r
+        else:
+            assert not any(send_c) and not any(recv_c)
+    for c in comms:
+        c.close()
+    for sh in shards + [whole]:
+        sh.close()
+
+
+def test_loopback_communicator_breaks_instead_of_hanging(gpu_required):
+    """A rank that never arrives must not hang its peers: with only ONE of two ranks calling, the loopback barrier
+    times out... that would take its full 60 s, so this test checks the cheap half -- bad arguments are refused before
+    any collective starts (the rule the sharded resample follows: everything fallible comes before the first one)."""
+    import ctypes as C
+
+    from conan_slam_amd import _capi
+    from conan_slam_amd.pf import LoopbackComm
+
+    L = _capi.lib()
+    arr = (C.c_void_p * 17)()
+    assert L.cslam_comm_create_loopback(C.c_int(17), C.c_int(-1), arr) == _capi.ERR_BAD_ARG
+    assert L.cslam_comm_create_loopback(C.c_int(0), C.c_int(-1), arr) == _capi.ERR_BAD_ARG
+    comms = LoopbackComm.create(2)
+    parts = _random_particles(8, 2, np.float32, seed=5)
+    sh = _shard_from(parts, 2, np.float32)
+    assert L.cslam_pf_resample_sharded(sh._h, comms[0]._h, None, C.c_double(6.0), C.c_int(1), None, None) == _capi.ERR_BAD_ARG
+    for c in comms:
+        c.close()
+    sh.close()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_fused_observation_step_equals_the_separate_calls(gpu_required, dtype):
     """cslam_pf_observation_step (one staged copy, nothing returned) against predict + sampleProposal + featureUpdate +
