@@ -53,15 +53,11 @@ struct EkfBase
     int         ldp      = 0; // padded leading dimension / column count
     int         n        = 3;
     int         sync_mode = 1;
-    int         tune_gain = 0; // env CSLAM_TUNE_GAIN: 0 explicit inverse in the factor kernel + MFMA product gain (shipped); 1 triangular-solve gain ekf_gain_solve_f32 (f32, 16 < k <= 64): measured factor 23.5 -> 18.7 us but gain 7.7 -> 18.3 us at N = 5000, k = 64
-    int         tune_downdate = 0; // env CSLAM_TUNE_DOWNDATE: 0 shipped (persistent symmetric; k<=64: memory ops inside the MFMA loop), 1 tile-per-workgroup full, 2 persistent symmetric unpipelined, 3 pipelined across tiles only, 4 first version
     int         seq_defer     = 1; // sequential update(): one P-GEMM per call (env CSLAM_SEQ_DEFER=0 restores m passes)
-    int         tune_factor   = 0; // env CSLAM_TUNE_FACTOR: 0 default (readlane one-wave up to k=64, workgroup-parallel up to 128 in f32, general beyond), 2 general always, 3 workgroup-parallel always, 5 blocked 2x2 (f32, 32<k<=64)
     int         lower         = 0; // block-lower storage of P (f32 default; env CSLAM_STORAGE=full|lower)
     int         pipeline      = 0; // P-GEMM of update t on stream B under the chain of update t+1 (env CSLAM_PIPELINE)
     int         pgemm_spare   = 16; // pipelined: workgroups the persistent P-GEMM grid leaves out (env CSLAM_PGEMM_SPARE)
     int         gather_corr_wide = 1; // a pending batch panel (<= 64 columns) corrected for inside the gather kernel (env CSLAM_GATHER_WIDE)
-    int         cu_split      = 0;  // pipelined: compute units reserved for the chain's stream by queue CU masks (env CSLAM_CU_SPLIT)
     int         pgemm_wgs     = 0;  // > 0: cap on the persistent P-GEMM grid (cslam_ekf_set_pgemm_workgroups: co-running instances)
     hipStream_t stream   = nullptr; // A: everything except the P-GEMM
     hipStream_t stream_b = nullptr; // B: the P-GEMM (== stream when not pipelined)
@@ -114,13 +110,9 @@ struct Ekf : EkfBase
     T*   dS    = nullptr;
     T*   dG    = nullptr;
     T*   dSub  = nullptr; // (3 + 64) x 64 compact block of PHT (see ekf_gather_kernel)
-    T*   dL    = nullptr; // solve mode: the factor L (64 x 64) and 1/diag(L) (64) of the last update
-    T*   dRdiag = nullptr;
     T*   dM    = nullptr; // 3 x 64: M = G G^T PHT[0:3,:]^T from ekf_factor_mfma_f32 (pose-stripe downdate in the gain kernel)
     bool m_valid = false; // the last factor launch produced dM
-    bool solve_gain = false; // the last factor launch published L instead of G (ekf_gain_solve_f32 follows)
     bool g_from_gt  = false; // the last factor launch wrote only G^T (ekf_factor_mfma_f32): debug transposes it
-    int  solve_K    = 0;
     bool sub_valid = false;
     T*   dGt   = nullptr;
     T*   dV    = nullptr;
@@ -140,9 +132,6 @@ struct Ekf : EkfBase
     bool        stage_ev_used[kStagingSlots];
     int         stage_next = 0;
     // tile list of the persistent symmetric downdate
-    long long* dStamps = nullptr; // CSLAM_FACTOR_STAMPS=1: in-kernel phase stamps of the factor kernel (diagnostic)
-    int   stamp_prints = 0;
-    long long* dPsymStamps = nullptr; // CSLAM_PSYM_STAMPS=1
     int*       dTicket     = nullptr; // two tile-ticket counters used alternately by successive P-GEMM launches
     // f32 P-GEMM on the bf16 matrix cores (ekf_pgemm_limbs.hpp): limb pairs per product (9 exact, 6, 0 = the f32 MFMA
     // kernel; env CSLAM_PGEMM_LIMBS), from how many columns on (env CSLAM_LIMBS_KMIN), the limb store and its size.
@@ -163,12 +152,7 @@ struct Ekf : EkfBase
     int        tilesM_built = 0;
     int        limb_parity = 0;
     unsigned   launch_parity = 0;
-    int        psym_nt = -1; // CSLAM_PSYM_NT: non-temporal P accesses in the P-GEMM (-1: by footprint)
-    int        psym_prefetch = -1; // CSLAM_PSYM_PREFETCH: software-pipelined LDS operands in the P-GEMM (-1: by chunk count)
-    unsigned long long* dHwIds = nullptr; // CSLAM_PSYM_HWID=1 (diagnostics)
-    int        hwid_prints = 0;
-    int        stagger_mode = 0, stagger_cycles = 0; // CSLAM_PSYM_STAGGER=mode,cycles
-    int   stamp_prints2 = 0;
+    int        psym_nt = -1; // CSLAM_PSYM_NT=0|1: non-temporal P accesses in the P-GEMM (-1: by footprint)
     int2* dTiles      = nullptr;
     int   tiles_built = 0;
     int   n_sym_tiles = 0;
@@ -223,9 +207,6 @@ struct Ekf : EkfBase
         free_workspace();
         (void)hipFree(dFlags);
         (void)hipFree(dHead);
-        (void)hipFree(dStamps);
-        (void)hipFree(dPsymStamps);
-        (void)hipFree(dHwIds);
         (void)hipFree(dTicket);
         (void)hipFree(dWb);
         (void)hipFree(dTilesM);
@@ -264,8 +245,6 @@ struct Ekf : EkfBase
         (void)hipFree(dS);
         (void)hipFree(dG);
         (void)hipFree(dSub);
-        (void)hipFree(dL);
-        (void)hipFree(dRdiag);
         (void)hipFree(dM);
         dM = nullptr;
         (void)hipFree(dGt);
@@ -274,7 +253,7 @@ struct Ekf : EkfBase
         (void)hipFree(dU);
         (void)hipFree(dScrS);
         (void)hipFree(dScrG);
-        dPHT = dS = dG = dSub = dL = dRdiag = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
+        dPHT = dS = dG = dSub = dGt = dV = dt_ = dU = dScrS = dScrG = nullptr;
     }
 
     int use_device() { CSLAM_HIP_TRY(hipSetDevice(device)); return CSLAM_OK; }
@@ -307,29 +286,8 @@ struct Ekf : EkfBase
             // the chain (A) outranks the P-GEMM (B): its small kernels must get in while the P-GEMM fills the chip
             int lo = 0, hi = 0;
             CSLAM_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            if (cu_split > 0)
-            {
-                // compute units partitioned between the two streams (queue CU masks): the chain's small kernels get
-                // cu_split units to themselves instead of crawling next to the P-GEMM's waves.  Mask bit i is unit
-                // i / 8 of XCD i % 8, so whole multiples of 8 take the same number of units from every XCD.
-                hipDeviceProp_t prop;
-                CSLAM_HIP_TRY(hipGetDeviceProperties(&prop, device));
-                const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-                cu_split      = std::min(std::max(8, (cu_split / 8) * 8), cus / 2);
-                const int words = (cus + 31) / 32;
-                std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
-                for (int i = 0; i < cus; i++)
-                {
-                    (i < cus - cu_split ? mb : ma)[i / 32] |= 1u << (i % 32);
-                }
-                CSLAM_HIP_TRY(hipExtStreamCreateWithCUMask(&stream, (uint32_t)words, ma.data()));
-                CSLAM_HIP_TRY(hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)words, mb.data()));
-            }
-            else
-            {
-                CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
-                CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream_b, hipStreamNonBlocking, lo));
-            }
+            CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+            CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream_b, hipStreamNonBlocking, lo));
         }
         else
         {
@@ -360,12 +318,8 @@ struct Ekf : EkfBase
         // allow the factor kernel its large dynamic LDS
         CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_kernel<T>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_par_kernel<T, 64>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (sizeof(T) == 4)
         {
-            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_par_kernel<T, 128>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_factor_mfma_big_f32<128>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
@@ -380,37 +334,11 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_downdate_f64<2>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
-        if (getenv("CSLAM_PSYM_STAMPS"))
-        {
-            CSLAM_HIP_TRY(hipMalloc(&dPsymStamps, 64 * sizeof(long long)));
-            CSLAM_HIP_TRY(hipMemsetAsync(dPsymStamps, 0, 64 * sizeof(long long), stream));
-        }
         CSLAM_HIP_TRY(hipMalloc(&dTicket, 2 * sizeof(int)));
         CSLAM_HIP_TRY(hipMemsetAsync(dTicket, 0, 2 * sizeof(int), stream));
         if (const char* sv = getenv("CSLAM_PSYM_NT"))
         {
-            psym_nt = atoi(sv);
-        }
-        if (const char* sv = getenv("CSLAM_PSYM_PREFETCH"))
-        {
-            psym_prefetch = atoi(sv);
-        }
-        if (getenv("CSLAM_PSYM_HWID"))
-        {
-            CSLAM_HIP_TRY(hipMalloc(&dHwIds, 4 * 1024 * sizeof(unsigned long long)));
-            CSLAM_HIP_TRY(hipMemsetAsync(dHwIds, 0, 4 * 1024 * sizeof(unsigned long long), stream));
-        }
-        if (const char* sv = getenv("CSLAM_PSYM_STAGGER"))
-        {
-            if (sscanf(sv, "%d,%d", &stagger_mode, &stagger_cycles) != 2)
-            {
-                stagger_mode = stagger_cycles = 0;
-            }
-        }
-        if (getenv("CSLAM_FACTOR_STAMPS"))
-        {
-            CSLAM_HIP_TRY(hipMalloc(&dStamps, 16 * sizeof(long long)));
-            CSLAM_HIP_TRY(hipMemsetAsync(dStamps, 0, 16 * sizeof(long long), stream));
+            psym_nt = atoi(sv) ? 1 : 0;
         }
         rc = ensure_k(64);
         if (rc)
@@ -449,8 +377,6 @@ struct Ekf : EkfBase
         if (dSub == nullptr)
         {
             CSLAM_HIP_TRY(hipMalloc(&dSub, (size_t)(3 + 64) * 64 * sizeof(T)));
-            CSLAM_HIP_TRY(hipMalloc(&dL, (size_t)64 * 64 * sizeof(T)));
-            CSLAM_HIP_TRY(hipMalloc(&dRdiag, (size_t)64 * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&dM, (size_t)3 * 128 * sizeof(T)));
         }
         CSLAM_HIP_TRY(hipMalloc(&dGt, kk));
@@ -666,13 +592,12 @@ struct Ekf : EkfBase
     // k8 columns go through ekf_downdate_psym4_f32 (see launch_downdate)
     bool psym4_takes(int k8) const
     {
-        return sizeof(T) == 4 && (k8 <= 128 || limbs_take(k8)) && lower && tune_downdate == 0 && ldp < 32768;
+        return sizeof(T) == 4 && (k8 <= 128 || limbs_take(k8)) && lower && ldp < 32768;
     }
     // ... or through ekf_downdate_psym5_bf16 (which pads its own limb store)
     bool limbs_take(int k8) const
     {
-        return sizeof(T) == 4 && pgemm_limbs > 0 && k8 >= limbs_kmin && k8 <= 256 && lower && tune_downdate == 0 &&
-               ldp < 32768;
+        return sizeof(T) == 4 && pgemm_limbs > 0 && k8 >= limbs_kmin && k8 <= 256 && lower && ldp < 32768;
     }
 
     int launch_negcol_fix(T* W, int kcols, hipStream_t st)
@@ -1149,13 +1074,10 @@ struct Ekf : EkfBase
         a.scratchS = dScrS;
         a.scratchG = dScrG;
         a.textbook = (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1;
-        a.stamps   = dStamps;
+        a.stamps   = nullptr;
         a.sub      = sub_valid ? dSub : nullptr;
-        a.dL       = nullptr;
-        a.dRdiag   = nullptr;
         a.dM       = nullptr;
         m_valid    = false;
-        solve_gain = false;
         g_from_gt  = false;
         a.pp       = fuse_now ? pp : PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
         a.P3       = dPv; // the pose block lives in the stripe
@@ -1163,174 +1085,78 @@ struct Ekf : EkfBase
         a.pred_out = dPred;
         a.lds_S    = 1;
         a.lds_G    = 1;
-        if constexpr (std::is_same<T, float>::value)
+        // Which kernel factorises S (all of them produce G^T, t, u; the tuned ones also M for the gain kernel's
+        // pose-stripe downdate):
+        //   k <= 16            ekf_factor_small_kernel: one wave, a row per lane, v_readlane broadcasts
+        //   16 < k <= 64       ekf_factor_mfma_f32 / _f64: rank-1 updates on the matrix cores
+        //   64 < k <= 128 f32  ekf_factor_mfma_big_f32: four 32-wide blocks
+        //   beyond             ekf_factor_kernel: the general LDS / global-scratch form
+        if (k <= 4)
         {
-            // 64 < k <= 128 (33..64 observations in one batch): the MFMA factor kernel with four 32-wide blocks
-            if (k > 64 && k <= 128 && tune_factor == 0)
-            {
-                constexpr int K = 128;
-                const size_t  lds = (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(float) +
-                                   (size_t)(K / 2 + 4) * sizeof(int) + 16;
-                a.dM      = dM;
-                m_valid   = (tune_gain == 0);
-                g_from_gt = true;
-                hipLaunchKernelGGL((ekf_factor_mfma_big_f32<128>), dim3(1), dim3(256), lds, stream, a, dU);
-                CSLAM_HIP_TRY(hipGetLastError());
-                if (dStamps && stamp_prints < 3)
-                {
-                    long long h[16];
-                    CSLAM_HIP_TRY(hipMemcpyAsync(h, dStamps, sizeof(h), hipMemcpyDeviceToHost, stream));
-                    CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-                    fprintf(stderr, "[cslam factor stamps k<=128, cycles] load+observe:%lld sums:%lld symmetrise+Tload:%lld cholesky:%lld inverse tail:%lld G^T:%lld t/u/M:%lld total:%lld\n",
-                            h[6] - h[0], h[7] - h[6], h[1] - h[7], h[2] - h[1], h[3] - h[2], h[9] - h[8], h[4] - h[9], h[4] - h[0]);
-                    stamp_prints++;
-                }
-                return CSLAM_OK;
-            }
+            a.dM    = dM;
+            m_valid = true;
+            hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
         }
+        else if (k <= 16)
         {
-            // workgroup-parallel factorisation (ekf_kernels_fast.hpp); K = 128 only fits LDS in f32
-            const int    kmaxp = (sizeof(T) == 4) ? 128 : 64;
-            const size_t elt   = sizeof(T);
-            auto lds_par = [&](int K) { return (size_t)(2 * K * (K + 1) + (K / 2) * 10 + 2 * K + 2) * elt + (K / 2 + 2) * 4 + 32; };
-            if (k <= kmaxp && (tune_factor == 3 || (tune_factor == 0 && k > 64)))
+            a.dM    = dM;
+            m_valid = true;
+            hipLaunchKernelGGL((ekf_factor_small_kernel<T, 16>), dim3(1), dim3(256), 0, stream, a, dU);
+        }
+        else if (k <= 64)
+        {
+            a.dM      = dM;
+            m_valid   = true;
+            g_from_gt = true;
+            if constexpr (std::is_same<T, float>::value)
             {
-                if (k <= 16)
+                if (k <= 32)
                 {
-                    hipLaunchKernelGGL((ekf_factor_par_kernel<T, 16>), dim3(1), dim3(64), lds_par(16), stream, a, dU);
-                }
-                else if (k <= 32)
-                {
-                    hipLaunchKernelGGL((ekf_factor_par_kernel<T, 32>), dim3(1), dim3(128), lds_par(32), stream, a, dU);
-                }
-                else if (k <= 64)
-                {
-                    hipLaunchKernelGGL((ekf_factor_par_kernel<T, 64>), dim3(1), dim3(256), lds_par(64), stream, a, dU);
+                    hipLaunchKernelGGL((ekf_factor_mfma_f32<32>), dim3(1), dim3(256), 0, stream, a, dU);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((ekf_factor_par_kernel<T, 128>), dim3(1), dim3(512), lds_par(128), stream, a, dU);
+                    hipLaunchKernelGGL((ekf_factor_mfma_f32<64>), dim3(1), dim3(256), 0, stream, a, dU);
                 }
-                CSLAM_HIP_TRY(hipGetLastError());
-                return CSLAM_OK;
-            }
-        }
-        if (launch_factor_blocked(a, k))
-        {
-            CSLAM_HIP_TRY(hipGetLastError());
-            if (dStamps && stamp_prints < 3)
-            {
-                long long h[16];
-                CSLAM_HIP_TRY(hipMemcpyAsync(h, dStamps, sizeof(h), hipMemcpyDeviceToHost, stream));
-                CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-                fprintf(stderr, "[cslam factor stamps, cycles]");
-                for (int i = 1; i <= 8; i++)
-                {
-                    fprintf(stderr, " %d:%lld", i, h[i] - h[i - 1]);
-                }
-                fprintf(stderr, " total:%lld\n", h[8] - h[0]);
-                stamp_prints++;
-            }
-            return CSLAM_OK;
-        }
-        if (k <= 64 && tune_factor != 2)
-        {
-            bool launched = false;
-            if constexpr (std::is_same<T, float>::value)
-            {
-                // rank-1 updates on the matrix cores (A/B: CSLAM_TUNE_FACTOR=1 selects the readlane kernel)
-                if (k > 16 && tune_factor == 0)
-                {
-                    if (tune_gain == 1) // experiment: the gain kernel applies inv(L) by substitution (publish L, skip the inverse)
-                    {
-                        a.dL       = dL;
-                        a.dRdiag   = dRdiag;
-                        solve_gain = true;
-                        solve_K    = (k <= 32) ? 32 : 64;
-                    }
-                    if (tune_gain == 0)
-                    {
-                        a.dM    = dM;
-                        m_valid = true;
-                    }
-                    if (k <= 32)
-                    {
-                        hipLaunchKernelGGL((ekf_factor_mfma_f32<32>), dim3(1), dim3(256), 0, stream, a, dU);
-                    }
-                    else
-                    {
-                        hipLaunchKernelGGL((ekf_factor_mfma_f32<64>), dim3(1), dim3(256), 0, stream, a, dU);
-                    }
-                    launched  = true;
-                    g_from_gt = true;
-                }
-            }
-            if constexpr (std::is_same<T, double>::value)
-            {
-                // the f64 counterpart on v_mfma_f64_16x16x4_f64 (A/B: CSLAM_TUNE_FACTOR=1 selects the readlane kernel)
-                if (k > 16 && tune_factor == 0)
-                {
-                    auto lds64 = [](int K) {
-                        return (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(double) +
-                               (size_t)(K / 2 + 4) * sizeof(int) + 16;
-                    };
-                    a.dM      = dM;
-                    m_valid   = true;
-                    g_from_gt = true;
-                    if (k <= 32)
-                    {
-                        hipLaunchKernelGGL((ekf_factor_mfma_f64<32>), dim3(1), dim3(256), lds64(32), stream, a, dU);
-                    }
-                    else
-                    {
-                        hipLaunchKernelGGL((ekf_factor_mfma_f64<64>), dim3(1), dim3(256), lds64(64), stream, a, dU);
-                    }
-                    launched = true;
-                }
-            }
-            // register-resident factorisation with v_readlane broadcasts
-            if (launched)
-            {
-            }
-            else if (k <= 4)
-            {
-                a.dM    = dM;
-                m_valid = true;
-                hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
-            }
-            else if (k <= 16)
-            {
-                a.dM    = dM;
-                m_valid = true;
-                hipLaunchKernelGGL((ekf_factor_small_kernel<T, 16>), dim3(1), dim3(256), 0, stream, a, dU);
-            }
-            else if (k <= 32)
-            {
-                hipLaunchKernelGGL((ekf_factor_small_kernel<T, 32>), dim3(1), dim3(256), 0, stream, a, dU);
             }
             else
             {
-                hipLaunchKernelGGL((ekf_factor_small_kernel<T, 64>), dim3(1), dim3(256), 0, stream, a, dU);
+                auto lds64 = [](int K) {
+                    return (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(double) +
+                           (size_t)(K / 2 + 4) * sizeof(int) + 16;
+                };
+                if (k <= 32)
+                {
+                    hipLaunchKernelGGL((ekf_factor_mfma_f64<32>), dim3(1), dim3(256), lds64(32), stream, a, dU);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((ekf_factor_mfma_f64<64>), dim3(1), dim3(256), lds64(64), stream, a, dU);
+                }
             }
-            CSLAM_HIP_TRY(hipGetLastError());
-            if (dStamps && stamp_prints < 3)
-            {
-                long long h[16];
-                CSLAM_HIP_TRY(hipMemcpyAsync(h, dStamps, sizeof(h), hipMemcpyDeviceToHost, stream));
-                CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-                fprintf(stderr, "[cslam factor stamps, cycles] build S:%lld (observe %lld, sums %lld, symmetrise+store %lld) cholesky:%lld (first half %lld) inverse:%lld outputs:%lld (check %lld, G %lld, t/u %lld) total:%lld\n",
-                        h[1] - h[0], h[6] - h[0], h[7] - h[6], h[1] - h[7], h[2] - h[1], h[5] ? h[5] - h[1] : 0, h[3] - h[2],
-                        h[4] - h[3], h[8] - h[3], h[9] - h[8], h[4] - h[9], h[4] - h[0]);
-                stamp_prints++;
-            }
-            return CSLAM_OK;
         }
-        size_t mat   = (size_t)k * (k + 1) * sizeof(T);
-        size_t small = ((size_t)m * 10 + k) * sizeof(T) + ((size_t)m + 4) * sizeof(int) + 64;
-        a.lds_S      = (mat + small <= kLdsBudget) ? 1 : 0;
-        a.lds_G      = (a.lds_S && 2 * mat + small <= kLdsBudget) ? 1 : 0;
-        size_t lds   = small + (a.lds_S ? mat : 0) + (a.lds_G ? mat : 0);
-        hipLaunchKernelGGL(ekf_factor_kernel<T>, dim3(1), dim3(kFactorThreads), lds, stream, a);
+        else if (std::is_same<T, float>::value && k <= 128)
+        {
+            if constexpr (std::is_same<T, float>::value)
+            {
+                constexpr int K   = 128;
+                const size_t  lds = (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(float) +
+                                   (size_t)(K / 2 + 4) * sizeof(int) + 16;
+                a.dM      = dM;
+                m_valid   = true;
+                g_from_gt = true;
+                hipLaunchKernelGGL((ekf_factor_mfma_big_f32<128>), dim3(1), dim3(256), lds, stream, a, dU);
+            }
+        }
+        else
+        {
+            size_t mat   = (size_t)k * (k + 1) * sizeof(T);
+            size_t small = ((size_t)m * 10 + k) * sizeof(T) + ((size_t)m + 4) * sizeof(int) + 64;
+            a.lds_S      = (mat + small <= kLdsBudget) ? 1 : 0;
+            a.lds_G      = (a.lds_S && 2 * mat + small <= kLdsBudget) ? 1 : 0;
+            size_t lds   = small + (a.lds_S ? mat : 0) + (a.lds_G ? mat : 0);
+            hipLaunchKernelGGL(ekf_factor_kernel<T>, dim3(1), dim3(kFactorThreads), lds, stream, a);
+        }
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -1341,24 +1167,13 @@ struct Ekf : EkfBase
     {
         const int n_pad    = round_up(n, kTile);
         pose_fused_in_gain = false;
-        if (launch_gain_fast(k, n_pad, slot))
+        if (!launch_gain_fast(k, n_pad, slot))
         {
-            CSLAM_HIP_TRY(hipGetLastError());
+            // the general vector-unit form (f32 beyond k = 128, f64 beyond k = 64): no X vector u, no fused pose downdate
+            hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
+                               slot, dX);
         }
-        else
-        {
-            if (k <= 64)
-            {
-                hipLaunchKernelGGL(ekf_gain_lds_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt,
-                                   dt_, slot, dX);
-            }
-            else
-            {
-                hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt,
-                                   dt_, slot, dX);
-            }
-            CSLAM_HIP_TRY(hipGetLastError());
-        }
+        CSLAM_HIP_TRY(hipGetLastError());
         if (pose_fused_in_gain)
         {
             return CSLAM_OK; // ekf_panel_mfma_f32 applied the pose-stripe downdate and zeroed the panel's pose rows itself
@@ -1371,7 +1186,6 @@ struct Ekf : EkfBase
     bool pose_fused_in_gain = false;
 
     int  launch_downdate(const T* W, int k, hipStream_t st);
-    bool launch_factor_blocked(const FactorArgs<T>& a, int k); // f32, 32 < k <= 64
     bool launch_corr_fast(int k, const T* Wp, int kc);          // PHT -= Wp*Y^T on MFMA (f32)
     int  ensure_tile_list(int tiles);
     bool launch_gain_fast(int k, int n_pad, T* slot); // MFMA gain (f32, k <= 128 where du is available)
@@ -1391,8 +1205,7 @@ struct Ekf : EkfBase
         const bool small_corr = kp > 0 && kp <= (gather_corr_wide ? kGatherCorrMax : kGatherCorr) && !pipeline;
         const bool wide_corr  = small_corr && kp > kGatherCorr;
         // a pending predict() rides along when this batch takes the (non-pipelined) fast path
-        fuse_now = pp.valid && (sizeof(T) == 4 || fuse_f64) && !pipeline && !keep_pending && k > 16 && k <= 64 && tune_factor == 0 &&
-                   tune_gain == 0;
+        fuse_now = pp.valid && (sizeof(T) == 4 || fuse_f64) && !pipeline && !keep_pending && k > 16 && k <= 64;
         if ((rc = fuse_now ? launch_pose_queue() : resolve_predict())) // (queued control steps come first either way)
         {
             return rc;
@@ -1433,7 +1246,7 @@ struct Ekf : EkfBase
         }
         const dim3 ggrid((n + 255) / 256, (m + kGatherObs - 1) / kGatherObs);
         // the compact H-rows block for the MFMA factor kernel (f32, 16 < k <= 64, no pending panels to correct)
-        sub_valid = (k > 16 && k <= 64 && (kp == 0 || small_corr) && tune_factor == 0 && dSub != nullptr);
+        sub_valid = (k > 16 && k <= 64 && (kp == 0 || small_corr) && dSub != nullptr);
         PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
         {
             T*             sub  = sub_valid ? dSub : nullptr;
@@ -1551,8 +1364,7 @@ struct Ekf : EkfBase
         }
         CSLAM_HIP_TRY(hipMemcpyAsync(dG, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         CSLAM_HIP_TRY(hipMemcpyAsync(dGt, Gt.data(), Gt.size() * sizeof(T), hipMemcpyHostToDevice, stream));
-        solve_gain = false; // the fallback gain is a general matrix: apply it with the product kernel
-        g_from_gt  = false;
+        g_from_gt  = false; // (the fallback gain is a general matrix, uploaded as G and G^T)
         m_valid    = false; // (M belonged to the zeroed G: the separate pose downdate kernel runs)
         CSLAM_HIP_TRY(hipMemcpyAsync(dt_, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice, stream));
         std::vector<T> u((size_t)k, (T)0);
@@ -1807,11 +1619,11 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipMemcpyAsync(S, dS, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
         }
-        if (G && !solve_gain && !g_from_gt)
+        if (G && !g_from_gt)
         {
             CSLAM_HIP_TRY(hipMemcpyAsync(G, dG, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
         }
-        if (G && !solve_gain && g_from_gt)
+        if (G && g_from_gt) // the tuned factor kernels publish only G^T (what the gain kernel reads)
         {
             std::vector<T> Gt((size_t)k * k);
             CSLAM_HIP_TRY(hipMemcpyAsync(Gt.data(), dGt, Gt.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
@@ -1822,42 +1634,6 @@ struct Ekf : EkfBase
                 for (int r = 0; r < k; r++)
                 {
                     out[(size_t)c * k + r] = Gt[(size_t)r * k + c];
-                }
-            }
-        }
-        if (G && solve_gain)
-        {
-            // solve mode never forms G on the device: G = inv(L) (REF_EXACT) or inv(L)^T (TEXTBOOK) from the
-            // published factor, by substitution in double precision
-            const int      K = solve_K;
-            std::vector<T> L((size_t)K * K);
-            int            fl[2] = {0, 0};
-            CSLAM_HIP_TRY(hipMemcpyAsync(L.data(), dL, L.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
-            CSLAM_HIP_TRY(hipMemcpyAsync(fl, dFlags, sizeof(fl), hipMemcpyDeviceToHost, stream));
-            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-            std::vector<double> X((size_t)k * k, 0.0); // inv(L), column-major k x k
-            if (fl[1] == 0)
-            {
-                for (int c = 0; c < k; c++)
-                {
-                    for (int r = c; r < k; r++)
-                    {
-                        double sacc = (r == c) ? 1.0 : 0.0;
-                        for (int q = c; q < r; q++)
-                        {
-                            sacc -= (double)L[(size_t)q * K + r] * X[(size_t)c * k + q];
-                        }
-                        X[(size_t)c * k + r] = sacc / (double)L[(size_t)r * K + r];
-                    }
-                }
-            }
-            const bool tb  = !(quirks & CSLAM_Q_LOWER_CHOL_GAIN);
-            T*         out = static_cast<T*>(G);
-            for (int c = 0; c < k; c++)
-            {
-                for (int r = 0; r < k; r++)
-                {
-                    out[(size_t)c * k + r] = (T)(tb ? X[(size_t)r * k + c] : X[(size_t)c * k + r]);
                 }
             }
         }
@@ -1904,64 +1680,49 @@ int Ekf<T>::ensure_tile_list(int tiles)
 template <>
 int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
 {
-    const int  tiles = round_up(n, kTile) / kTile;
-    const dim3 grid(tiles * tiles), block(256);
-    const int  k8 = round_up(k, 8); // W columns [k, k8) are zero (flush() clears the tail)
-    if (tune_downdate == 1) // A/B: one workgroup per tile, register-staged panels, full (non-symmetric) computation
+    const int tiles = round_up(n, kTile) / kTile;
+    const int k8    = round_up(k, 8); // W columns [k, k8) are zero where the kernel reads them (flush() clears the tail)
+    // persistent symmetric kernels over the list of lower-triangular tiles; mirror stores only under full storage
+    int rc = ensure_tile_list(tiles);
+    if (rc)
     {
-        hipLaunchKernelGGL((ekf_downdate2_f32<32, true>), grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
+        return rc;
     }
-    else if (tune_downdate == 4) // A/B: the first version
+    const dim3 block(256);
+    // Persistent grid: two workgroups per CU, minus `pgemm_spare` in two-stream mode -- a few CUs keep one workgroup
+    // (64 of 160 KB LDS) so that the one-workgroup factor kernel of the NEXT update (53 KB LDS, stream A) finds room
+    // while this P-GEMM fills the chip.
+    int G = std::min(n_sym_tiles, std::max(1, 2 * num_cus - (pipeline ? pgemm_spare : 0)));
+    if (pgemm_wgs > 0)
     {
-        hipLaunchKernelGGL(ekf_downdate_f32, grid, block, 0, stream, dP, ldp, W, ldp, k, tiles);
+        G = std::min(G, pgemm_wgs);
     }
-    else
+    const bool nt = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
+    if (limbs_take(k8))
     {
-        // persistent symmetric kernels (tile list); mirror stores only under full storage
-        int rc = ensure_tile_list(tiles);
-        if (rc)
+        // f32 products as exact bf16 limb products on the bf16 matrix cores (ekf_pgemm_limbs.hpp)
+        const int    nch  = k8 <= 64 ? 4 : (k8 <= 96 ? 6 : (k8 <= 128 ? 8 : (k8 <= 192 ? 12 : 16)));
+        const int    kgs  = 2 * nch;
+        const int    rows = round_up(n, kTile);
+        const size_t need = (size_t)2 * 3 * kgs * rows * 16;
+        if (need > wb_bytes)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // (grows with n and the window: rare)
+            (void)hipFree(dWb);
+            dWb      = nullptr;
+            wb_bytes = 0;
+            const size_t cap = (size_t)2 * 3 * 32 * round_up(ncap, kTile) * 16; // every window up to 256 columns
+            CSLAM_HIP_TRY(hipMalloc(&dWb, cap));
+            wb_bytes = cap;
+        }
+        if ((rc = ensure_tiles_morton(tiles, stream)))
         {
             return rc;
         }
-        // Persistent grid: two workgroups per CU, minus `pgemm_spare` -- a few CUs keep one workgroup (64 of 160 KB LDS)
-        // so that the one-workgroup factor kernel of the NEXT update (53 KB LDS, stream A) finds room while this P-GEMM
-        // fills the chip (pipelined mode).
-        int G = std::min(n_sym_tiles, std::max(1, 2 * num_cus - (pipeline ? pgemm_spare : 0)));
-        if (pipeline && cu_split > 0 && stream != this->stream)
-        {
-            G = std::min(n_sym_tiles, 2 * (num_cus - cu_split)); // its stream owns that many compute units
-        }
-        if (pgemm_wgs > 0)
-        {
-            G = std::min(G, pgemm_wgs);
-        }
-        if (limbs_take(k8))
-        {
-            // f32 products as exact bf16 limb products on the bf16 matrix cores (ekf_pgemm_limbs.hpp)
-            const int    nch  = k8 <= 64 ? 4 : (k8 <= 96 ? 6 : (k8 <= 128 ? 8 : (k8 <= 192 ? 12 : 16)));
-            const int    kgs  = 2 * nch;
-            const int    rows = round_up(n, kTile);
-            const size_t need = (size_t)2 * 3 * kgs * rows * 16;
-            if (need > wb_bytes)
-            {
-                CSLAM_HIP_TRY(hipStreamSynchronize(stream)); // (grows with n and the window: rare)
-                (void)hipFree(dWb);
-                dWb      = nullptr;
-                wb_bytes = 0;
-                const size_t cap = (size_t)2 * 3 * 32 * round_up(ncap, kTile) * 16; // every window up to 256 columns
-                CSLAM_HIP_TRY(hipMalloc(&dWb, cap));
-                wb_bytes = cap;
-            }
-            if ((rc = ensure_tiles_morton(tiles, stream)))
-            {
-                return rc;
-            }
-            hipLaunchKernelGGL(ekf_limb_split_kernel, dim3((rows + 255) / 256, kgs), dim3(256), 0, stream, W, ldp, k, rows, kgs,
-                               dWb);
-            // (ring of 3 panel buffers, 72 KB: two workgroups per compute unit; a ring of 6 at one workgroup per unit
-            // was measured at 365 - 443 us and is not instantiated)
-            limb_parity ^= 1;
-            const bool nt = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
+        hipLaunchKernelGGL(ekf_limb_split_kernel, dim3((rows + 255) / 256, kgs), dim3(256), 0, stream, W, ldp, k, rows, kgs,
+                           dWb);
+        // (ring of 3 panel buffers, 72 KB: two workgroups per compute unit)
+        limb_parity ^= 1;
 #define CSLAM_LAUNCH_PSYM5(MODE, NCH, NP, RR)                                                                          \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -1988,163 +1749,64 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
             if (nt) { CSLAM_LAUNCH_PSYM5(1, NCH, 9, RR); } else { CSLAM_LAUNCH_PSYM5(0, NCH, 9, RR); }                 \
         }                                                                                                              \
     } while (0)
-            switch (nch)
-            {
-            case 4: CSLAM_LAUNCH_PSYM5R(4, 3); break;
-            case 6: CSLAM_LAUNCH_PSYM5R(6, 3); break;
-            case 8: CSLAM_LAUNCH_PSYM5R(8, 3); break;
-            case 12: CSLAM_LAUNCH_PSYM5R(12, 3); break;
-            default: CSLAM_LAUNCH_PSYM5R(16, 3); break;
-            }
+        switch (nch)
+        {
+        case 4: CSLAM_LAUNCH_PSYM5R(4, 3); break;
+        case 6: CSLAM_LAUNCH_PSYM5R(6, 3); break;
+        case 8: CSLAM_LAUNCH_PSYM5R(8, 3); break;
+        case 12: CSLAM_LAUNCH_PSYM5R(12, 3); break;
+        default: CSLAM_LAUNCH_PSYM5R(16, 3); break;
+        }
 #undef CSLAM_LAUNCH_PSYM5R
 #undef CSLAM_LAUNCH_PSYM5
-        }
-        else if (k8 <= 128 && lower && tune_downdate == 0 && ldp < 32768)
+    }
+    else if (k8 <= 128 && lower && ldp < 32768)
+    {
+        // the shipped P-GEMM: every memory operation interleaved with the MFMA loop; two chunks of 32 columns (k <= 64),
+        // four of 24 (k <= 96) or four of 32 (k <= 128)
+        launch_parity++;
+        // per-XCD tile queues (see the kernel): env CSLAM_XCD_QUEUES (every queue needs workgroups: small grids stay on
+        // the single queue)
+        const bool xq = xcd_queues != 0 && G >= 64;
+        if (xq)
         {
-            // every memory operation interleaved with the MFMA loop; two (k <= 64) or four (k <= 128) chunks of 32
-            launch_parity++;
-            // per-XCD tile queues (see the kernel): env CSLAM_XCD_QUEUES
-            // (every queue needs workgroups: small grids stay on the single queue)
-            const bool xq = xcd_queues != 0 && dHwIds == nullptr && G >= 64;
-            if (xq)
+            if ((rc = ensure_tiles_morton(tiles, stream)))
             {
-                if ((rc = ensure_tiles_morton(tiles, stream)))
-                {
-                    return rc;
-                }
-                limb_parity ^= 1;
+                return rc;
             }
-            const bool nt     = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
-            const int  ntmode = psym_nt >= 0 ? psym_nt : (nt ? 1 : 0);
-#define CSLAM_LAUNCH_PSYM4X(MODE, NCH, KC, PF)                                                                        \
-    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE, NCH, KC, PF>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k,     \
+            limb_parity ^= 1;
+        }
+#define CSLAM_LAUNCH_PSYM4(MODE, NCH, KC)                                                                             \
+    hipLaunchKernelGGL((ekf_downdate_psym4_f32<MODE, NCH, KC>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k,         \
                        xq ? (const int2*)dTilesM : (const int2*)dTiles, n_sym_tiles,                                  \
                        xq ? dTicketX + 8 * limb_parity : dTicket + (launch_parity & 1),                              \
-                       xq ? dTicketX + 8 * (limb_parity ^ 1) : dTicket + ((launch_parity + 1) & 1), dHwIds,          \
-                       xq ? (const int*)dSegOff : (const int*)nullptr)
-#define CSLAM_LAUNCH_PSYM4(MODE, NCH) CSLAM_LAUNCH_PSYM4X(MODE, NCH, 32, false)
-            // software-pipelined LDS operands (see the kernel): an A/B switch, CSLAM_PSYM_PREFETCH=1
-            // (measured, N = 5000: k = 128 119.3 vs 119.4 us, k = 64 80.6 vs 85.5 us without / with: two waves per SIMD
-            // already hide the LDS latency, so it stays off)
-            const bool pf4 = psym_prefetch > 0;
-            const bool pf2 = psym_prefetch > 0;
-            if (k8 <= 64 && pf2 && ntmode <= 1)
-            {
-                if (ntmode == 1) { CSLAM_LAUNCH_PSYM4X(1, 2, 32, true); }
-                else { CSLAM_LAUNCH_PSYM4X(0, 2, 32, true); }
-            }
-            else if (k8 <= 64)
-            {
-                if (ntmode == 1) { CSLAM_LAUNCH_PSYM4(1, 2); }
-                else if (ntmode == 2) { CSLAM_LAUNCH_PSYM4(2, 2); }
-                else if (ntmode == 3) { CSLAM_LAUNCH_PSYM4(3, 2); }
-                else if (ntmode == 4) { CSLAM_LAUNCH_PSYM4(4, 2); }
-                else if (ntmode == 5) { CSLAM_LAUNCH_PSYM4(5, 2); }
-                else if (ntmode == 6) { CSLAM_LAUNCH_PSYM4(6, 2); }
-                else { CSLAM_LAUNCH_PSYM4(0, 2); }
-            }
-            else if (k8 <= 96) // four chunks of 24
-            {
-                if (ntmode == 1)
-                {
-                    if (pf4) { CSLAM_LAUNCH_PSYM4X(1, 4, 24, true); } else { CSLAM_LAUNCH_PSYM4X(1, 4, 24, false); }
-                }
-                else
-                {
-                    if (pf4) { CSLAM_LAUNCH_PSYM4X(0, 4, 24, true); } else { CSLAM_LAUNCH_PSYM4X(0, 4, 24, false); }
-                }
-            }
-            else
-            {
-                if (ntmode == 1)
-                {
-                    if (pf4) { CSLAM_LAUNCH_PSYM4X(1, 4, 32, true); } else { CSLAM_LAUNCH_PSYM4X(1, 4, 32, false); }
-                }
-                else
-                {
-                    if (pf4) { CSLAM_LAUNCH_PSYM4X(0, 4, 32, true); } else { CSLAM_LAUNCH_PSYM4X(0, 4, 32, false); }
-                }
-            }
-#undef CSLAM_LAUNCH_PSYM4X
-#undef CSLAM_LAUNCH_PSYM4
-        }
-        else if (k8 <= 64 && tune_downdate != 2)
+                       xq ? dTicketX + 8 * (limb_parity ^ 1) : dTicket + ((launch_parity + 1) & 1),                  \
+                       (unsigned long long*)nullptr, xq ? (const int*)dSegOff : (const int*)nullptr)
+        if (k8 <= 64)
         {
-            launch_parity++;
-            const bool nt = psym_nt >= 0 ? psym_nt != 0 : (size_t)n_sym_tiles * 65536 > ((size_t)230 << 20);
-            if (lower && !nt)
-            {
-                hipLaunchKernelGGL((ekf_downdate_psym3_f32<false, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                                   tiles_built, n_sym_tiles, dTicket + (launch_parity & 1),
-                                   dTicket + ((launch_parity + 1) & 1), stagger_mode, stagger_cycles, dHwIds);
-            }
-            else if (lower)
-            {
-                hipLaunchKernelGGL((ekf_downdate_psym3_f32<true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                                   tiles_built, n_sym_tiles, dTicket + (launch_parity & 1),
-                                   dTicket + ((launch_parity + 1) & 1), stagger_mode, stagger_cycles, dHwIds);
-            }
-            else
-            {
-                hipLaunchKernelGGL((ekf_downdate_psym3_f32<true, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                                   tiles_built, n_sym_tiles, dTicket + (launch_parity & 1),
-                                   dTicket + ((launch_parity + 1) & 1), stagger_mode, stagger_cycles, dHwIds);
-            }
-            if (dHwIds && hwid_prints < 3)
-            {
-                hwid_prints++;
-                std::vector<unsigned long long> h(4 * G);
-                CSLAM_HIP_TRY(hipMemcpyAsync(h.data(), dHwIds, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost, stream));
-                CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-                // per-workgroup start / end (s_memtime) relative to the earliest start, grouped by tile count
-                unsigned long long t0 = ~0ull, t1 = 0;
-                for (int i = 0; i < G; i++)
-                {
-                    t0 = std::min(t0, h[4 * i + 2]);
-                    t1 = std::max(t1, h[4 * i + 3]);
-                }
-                double s_start = 0, s_end = 0, mx_start = 0, mn_end = 1e30;
-                for (int i = 0; i < G; i++)
-                {
-                    const double st = (double)(h[4 * i + 2] - t0), en = (double)(h[4 * i + 3] - t0);
-                    s_start += st;
-                    s_end += en;
-                    mx_start = std::max(mx_start, st);
-                    mn_end   = std::min(mn_end, en);
-                }
-                fprintf(stderr, "[cslam] psym3 timeline (10 ns ticks): span %llu | start avg %.0f max %.0f | end min %.0f avg %.0f\n",
-                        t1 - t0, s_start / G, mx_start, mn_end, s_end / G);
-                fprintf(stderr, "[cslam] sample (wg: xcc start end):");
-                for (int i = 0; i < G; i += 32)
-                {
-                    fprintf(stderr, " %d:%llu %llu %llu", i, h[4 * i + 1] & 15, h[4 * i + 2] - t0, h[4 * i + 3] - t0);
-                }
-                fprintf(stderr, "\n");
-            }
+            if (nt) { CSLAM_LAUNCH_PSYM4(1, 2, 32); } else { CSLAM_LAUNCH_PSYM4(0, 2, 32); }
         }
-        else if (lower)
+        else if (k8 <= 96)
         {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                               dTiles, n_sym_tiles, dPsymStamps);
+            if (nt) { CSLAM_LAUNCH_PSYM4(1, 4, 24); } else { CSLAM_LAUNCH_PSYM4(0, 4, 24); }
         }
         else
         {
-            hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8,
-                               dTiles, n_sym_tiles, dPsymStamps);
+            if (nt) { CSLAM_LAUNCH_PSYM4(1, 4, 32); } else { CSLAM_LAUNCH_PSYM4(0, 4, 32); }
         }
-        if (dPsymStamps && stamp_prints2 < 2)
-        {
-            long long h[64];
-            CSLAM_HIP_TRY(hipMemcpyAsync(h, dPsymStamps, sizeof(h), hipMemcpyDeviceToHost, stream));
-            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
-            fprintf(stderr, "[cslam psym stamps, cycles per phase: wait-top | dma | mfma | epilogue+next]\n");
-            for (int t = 0; t + 4 < 28; t += 4)
-            {
-                fprintf(stderr, "  tile %d: %lld | %lld | %lld | %lld\n", t / 4, h[t + 1] - h[t], h[t + 2] - h[t + 1],
-                        h[t + 3] - h[t + 2], h[t + 4] - h[t + 3]);
-            }
-            stamp_prints2++;
-        }
+#undef CSLAM_LAUNCH_PSYM4
+    }
+    else if (lower)
+    {
+        // any k, block-lower storage: the unpipelined persistent symmetric kernel (windows beyond 128 columns)
+        hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, false>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8, dTiles,
+                           n_sym_tiles, (long long*)nullptr);
+    }
+    else
+    {
+        // full storage (CSLAM_STORAGE=full): the same kernel with mirror stores
+        hipLaunchKernelGGL((ekf_downdate_psym_f32<64, true, true>), dim3(G), block, 0, stream, dP, ldp, W, ldp, k8, dTiles,
+                           n_sym_tiles, (long long*)nullptr);
     }
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
@@ -2153,28 +1815,9 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
 template <>
 bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot)
 {
-    if (solve_gain) // the factor kernel published L: W1 by substitution, X += W1 * t fused
+    if (k > 128)
     {
-        const bool tb   = !(quirks & CSLAM_Q_LOWER_CHOL_GAIN);
-        const int  k8   = round_up(k, 8);
-        const dim3 grid((n_pad + 255) / 256), block(256);
-#define CSLAM_LAUNCH_SOLVE(KK, TB)                                                                                   \
-    hipLaunchKernelGGL((ekf_gain_solve_f32<KK, TB>), grid, block, 0, stream, dPHT, ldp, n, n_pad, k, k8, dL, dRdiag, dV, \
-                       dFlags, slot, ldp, dX)
-        if (solve_K == 32)
-        {
-            if (tb) { CSLAM_LAUNCH_SOLVE(32, true); } else { CSLAM_LAUNCH_SOLVE(32, false); }
-        }
-        else
-        {
-            if (tb) { CSLAM_LAUNCH_SOLVE(64, true); } else { CSLAM_LAUNCH_SOLVE(64, false); }
-        }
-#undef CSLAM_LAUNCH_SOLVE
-        return true;
-    }
-    if (k > 128 || (k > 64 && tune_factor != 0 && tune_factor != 3))
-    {
-        return false; // du is produced by the tuned factor kernels only
+        return false; // u is produced by the tuned factor kernels only
     }
     hipLaunchKernelGGL((ekf_panel_mfma_f32<false, true>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n,
                        k, k, dGt, k, dU, slot, ldp, dX, fuse_now ? (const float*)dPred : (const float*)nullptr, pp.w, dPv, ldp,
@@ -2202,26 +1845,9 @@ bool Ekf<double>::launch_corr_fast(int k, const double* Wp, int kc)
 }
 
 template <>
-bool Ekf<float>::launch_factor_blocked(const FactorArgs<float>& a, int k)
-{
-    if (k <= 32 || k > 64 || tune_factor != 5)
-    {
-        return false; // experiment only: measured no faster than the one-wave kernel
-    }
-    hipLaunchKernelGGL(ekf_factor_blocked64_f32, dim3(1), dim3(256), 0, stream, a, dU);
-    return true;
-}
-
-template <>
-bool Ekf<double>::launch_factor_blocked(const FactorArgs<double>&, int)
-{
-    return false;
-}
-
-template <>
 bool Ekf<double>::launch_gain_fast(int k, int n_pad, double* slot)
 {
-    if (k > 64 || tune_factor != 0) // du (and M) come from the tuned factor kernels
+    if (k > 64) // u (and M) come from the tuned factor kernels
     {
         return false;
     }
@@ -2352,14 +1978,6 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     {
         b->seq_defer = atoi(sd);
     }
-    if (const char* tf = getenv("CSLAM_TUNE_FACTOR"))
-    {
-        b->tune_factor = atoi(tf);
-    }
-    if (const char* tv = getenv("CSLAM_TUNE_DOWNDATE"))
-    {
-        b->tune_downdate = atoi(tv);
-    }
     if (const char* ff = getenv("CSLAM_FUSE_F64"))
     {
         b->fuse_f64 = atoi(ff) ? 1 : 0;
@@ -2368,24 +1986,12 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     {
         b->set_fuse_predict(atoi(fp));
     }
-    if (const char* tg = getenv("CSLAM_TUNE_GAIN"))
-    {
-        b->tune_gain = atoi(tg);
-    }
-    // Block-lower storage: only 128x128 tiles on/below the tile diagonal of the symmetric P are maintained
-    // (the P-GEMM then writes each tile once).  Needs the persistent symmetric kernel -> f32 default path only.
-    b->lower = (dtype == CSLAM_F64 || b->tune_downdate == 0 || b->tune_downdate == 2 || b->tune_downdate == 3) ? 1 : 0;
+    // Block-lower storage (default): only the 128x128 tiles on / below the tile diagonal of the symmetric P are maintained
+    // (the P-GEMM writes each tile once).  CSLAM_STORAGE=full keeps both triangles (mirror stores in the P-GEMM).
+    b->lower = 1;
     if (const char* sv = getenv("CSLAM_STORAGE"))
     {
-        if (!strcmp(sv, "full"))
-        {
-            b->lower = 0;
-        }
-        else if (!strcmp(sv, "lower") &&
-                 (dtype == CSLAM_F64 || b->tune_downdate == 0 || b->tune_downdate == 2 || b->tune_downdate == 3))
-        {
-            b->lower = 1;
-        }
+        b->lower = strcmp(sv, "full") ? 1 : 0;
     }
     // two-stream pipelining (see the top of this file) is an option, not the default: measured at N = 5000, k = 64
     // (profiles/r02_*): the kernels of update t+1 that touch memory crawl underneath the persistent P-GEMM (its waves
@@ -2411,10 +2017,6 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     if (const char* gw = getenv("CSLAM_GATHER_WIDE"))
     {
         b->gather_corr_wide = atoi(gw) ? 1 : 0;
-    }
-    if (const char* cs = getenv("CSLAM_CU_SPLIT"))
-    {
-        b->cu_split = std::max(0, atoi(cs));
     }
     if (const char* sp = getenv("CSLAM_PGEMM_SPARE"))
     {

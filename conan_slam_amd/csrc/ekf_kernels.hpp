@@ -866,8 +866,6 @@ struct FactorArgs
     T*         scratchG;
     long long* stamps; // diagnostic: s_memtime at phase boundaries (nullptr in production)
     const T*   sub;    // compact (3+2m) x 2m block of PHT written by ekf_gather_kernel, or nullptr
-    T*         dL;     // solve mode (ekf_gain_solve_f32): the factor L (K x K) is published instead of G; or nullptr
-    T*         dRdiag; // 1 / diag(L), K values
     T*         dM;     // optional (ekf_factor_mfma_f32): M = G*(G^T*PHT[0:3,:]^T), 3 x k (row c at dM + c*k): the gain kernel
                        // then applies the pose-stripe downdate P[:,0:3] -= W1*W1[0:3,:]^T = PHT*M itself (see ekf_panel_mfma_f32)
     PredictArgs<T> pp;   // pending predict (valid = 0: none); honoured by ekf_factor_mfma_f32 / ekf_factor_mfma_f64 only
@@ -1145,210 +1143,6 @@ __global__ void __launch_bounds__(256) ekf_gain_kernel(const T* __restrict__ PHT
         s += s_part[2][ri];
         s += s_part[3][ri];
         X[i] = X[i] + s;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4 for k <= 64 (the f64 path and the small f32 batches): same thread mapping, same sums in the same order as
-// ekf_gain_kernel, but the kernel above is a chain of 8 + 64 dependent round trips (PHT in chunks, G^T through
-// scalar loads): 50 us at n = 2003, k = 64 in f64.  Here every PHT value of the row is requested up front and G^T
-// is staged in LDS once: two round trips, then 1024 multiply-adds per thread fed by broadcast LDS reads.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) ekf_gain_lds_kernel(const T* __restrict__ PHT, int ldw, int n, int n_pad, int k,
-                                                            const T* __restrict__ Gt, const T* __restrict__ t,
-                                                            T* __restrict__ W1, T* __restrict__ X)
-{
-    constexpr int KM = 64;
-    __shared__ T  s_g[KM * KM]; // G^T, k x k, row q contiguous
-    __shared__ T  s_part[4][64];
-    const int     ri = threadIdx.x & 63;
-    const int     cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int     i  = blockIdx.x * 64 + ri;
-    const bool    in = (i < n);
-    const int     ii = in ? i : 0;
-    T             pv[KM];
-#pragma unroll
-    for (int q0 = 0; q0 < KM; q0 += 8)
-    {
-        if (q0 < k) // (uniform: small batches request one chunk)
-        {
-#pragma unroll
-            for (int q = q0; q < q0 + 8; q++)
-            {
-                pv[q] = PHT[(size_t)((q < k) ? q : (k - 1)) * ldw + ii];
-            }
-        }
-    }
-    for (int e = threadIdx.x; e < k * k; e += 256)
-    {
-        s_g[e] = Gt[e];
-    }
-    __syncthreads();
-    const int c0 = cg * kGainCols;
-    T         xs = (T)0;
-    if (c0 < k)
-    {
-        T acc[kGainCols];
-#pragma unroll
-        for (int cc = 0; cc < kGainCols; cc++)
-        {
-            acc[cc] = (T)0;
-        }
-        if (c0 + kGainCols <= k)
-        {
-            // all 16 columns exist: plain reads, no selects (with them every LDS read was waited for on its own)
-#pragma unroll
-            for (int q = 0; q < KM; q++)
-            {
-                if (q < k)
-                {
-                    const T  p  = in ? pv[q] : (T)0;
-                    const T* gr = &s_g[q * k + c0];
-                    T        g[kGainCols];
-#pragma unroll
-                    for (int cc = 0; cc < kGainCols; cc++)
-                    {
-                        g[cc] = gr[cc];
-                    }
-#pragma unroll
-                    for (int cc = 0; cc < kGainCols; cc++)
-                    {
-                        acc[cc] += p * g[cc];
-                    }
-                }
-            }
-        }
-        else
-        {
-#pragma unroll
-            for (int q = 0; q < KM; q++)
-            {
-                if (q < k)
-                {
-                    const T  p  = in ? pv[q] : (T)0;
-                    const T* gr = &s_g[q * k + c0];
-#pragma unroll
-                    for (int cc = 0; cc < kGainCols; cc++)
-                    {
-                        const bool ok = (c0 + cc < k);
-                        const T    g  = gr[ok ? cc : 0];
-                        acc[cc] += p * (ok ? g : (T)0);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int cc = 0; cc < kGainCols; cc++)
-        {
-            if (c0 + cc < k)
-            {
-                if (i < n_pad)
-                {
-                    W1[(size_t)(c0 + cc) * ldw + i] = in ? acc[cc] : (T)0;
-                }
-                xs += acc[cc] * t[c0 + cc];
-            }
-        }
-    }
-    s_part[cg][ri] = xs;
-    __syncthreads();
-    if (cg == 0 && in)
-    {
-        T s = s_part[0][ri];
-        s += s_part[1][ri];
-        s += s_part[2][ri];
-        s += s_part[3][ri];
-        X[i] = X[i] + s;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K5 (f32): P -= W1 * W1^T  (slam.h:260) -- the P-GEMM.
-// Workgroup = 4 waves, tile = 128 rows x 128 cols of P; wave w owns columns [32w, 32w+32) and all 128
-// rows as FOUR interleaved 32x32 MFMA tiles: MFMA column index j (the lane) <-> P rows 4j+b, b = 0..3,
-// so that every global access of P is a 16-byte-per-lane load/store of 4 consecutive rows (512
-// contiguous bytes per half-wave) and the B operand of all four tiles is one ds_read_b128.
-// v_mfma_f32_32x32x2_f32: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
-// D[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31] in register r.  Here i <-> P column, j <-> P row.
-// The product is accumulated from zero and subtracted once, as the reference does (temporary, then P - tmp).
-// W1 panels of the tile's rows and columns are staged through LDS in k-chunks of KC.
-// ------------------------------------------------------------------------------------------------
-constexpr int kDownKC = 32;
-
-__global__ void __launch_bounds__(256, 3) ekf_downdate_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
-                                                            int ldw, int k, int tiles)
-{
-    __shared__ __attribute__((aligned(16))) float s_pan[2 * kDownKC * 128]; // [0]: row panel, [1]: column panel
-    float* sB = s_pan;
-    float* sA = s_pan + kDownKC * 128;
-
-    const int tid  = threadIdx.x;
-    const int wave = tid >> 6;
-    const int lane = tid & 63;
-    const int lj   = lane & 31;
-    const int lh   = lane >> 5;
-    const int tj   = blockIdx.x / tiles; // column tile (shared by consecutive workgroups)
-    const int ti   = blockIdx.x % tiles; // row tile
-    const int row0 = ti * 128;
-    const int col0 = tj * 128;
-
-    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-
-    for (int k0 = 0; k0 < k; k0 += kDownKC)
-    {
-        const int kc = min(kDownKC, k - k0);
-        if (k0 > 0)
-        {
-            __syncthreads();
-        }
-        for (int id = tid; id < kc * 32; id += 256)
-        {
-            const int    kk = id >> 5;
-            const int    r4 = (id & 31) * 4;
-            const float* w  = W1 + (size_t)(k0 + kk) * ldw;
-            float4       vb = *reinterpret_cast<const float4*>(w + row0 + r4);
-            float4       va = *reinterpret_cast<const float4*>(w + col0 + r4);
-            *reinterpret_cast<float4*>(&sB[kk * 128 + r4]) = vb;
-            *reinterpret_cast<float4*>(&sA[kk * 128 + r4]) = va;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < kc; kk += 2)
-        {
-            const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + lh) * 128 + 4 * lj]);
-            const float  a = sA[(kk + lh) * 128 + wave * 32 + lj];
-            acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
-            acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
-            acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
-            acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
-        }
-    }
-    // epilogue: all loads of a half-tile are issued before the first store, so that 8 x 1 KiB per wave
-    // are in flight (a load placed after a store to the same array would be serialised behind it)
-#pragma unroll
-    for (int half = 0; half < 2; half++)
-    {
-        float4* ptr[8];
-        float4  v[8];
-#pragma unroll
-        for (int rr = 0; rr < 8; rr++)
-        {
-            const int r   = half * 8 + rr;
-            const int col = col0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            ptr[rr]       = reinterpret_cast<float4*>(P + (size_t)col * ldp + row0 + 4 * lj);
-            v[rr]         = *ptr[rr];
-        }
-#pragma unroll
-        for (int rr = 0; rr < 8; rr++)
-        {
-            const int r = half * 8 + rr;
-            v[rr].x -= acc0[r];
-            v[rr].y -= acc1[r];
-            v[rr].z -= acc2[r];
-            v[rr].w -= acc3[r];
-            *ptr[rr] = v[rr];
-        }
     }
 }
 

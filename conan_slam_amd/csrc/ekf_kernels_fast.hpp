@@ -11,12 +11,15 @@
 //                                 tickets, every memory operation issued from inside the MFMA loop; NCH = 2 (k <= 64)
 //                                 or 4 (k <= 128) chunks of 32 columns.
 //   (predict, heading, augment and the pose-stripe downdate live in ekf_pose_kernels.hpp)
-// Other shapes, A/B switches and earlier generations (selected by the CSLAM_TUNE_* variables, see cslam_ekf.hip):
-//   ekf_factor_small_kernel<T,K>  one wave holds the matrix a row per lane; every multiplier broadcast by v_readlane
-//                                 (k <= 16, and f64).
-//   ekf_factor_par_kernel, ekf_factor_blocked64_f32   workgroup-parallel / 2x2-blocked factorisations.
-//   ekf_gain_solve_f32            W1 by triangular substitution (no inverse): correct, slower end to end.
-//   ekf_downdate_psym3_f32, ekf_downdate_psym_f32, ekf_downdate2_f32   earlier P-GEMM generations.
+// Other shapes:
+//   ekf_factor_small_kernel<T,K>  k <= 16: one wave holds the matrix a row per lane; every multiplier broadcast by v_readlane.
+//   ekf_factor_mfma_f64<K>        the f64 counterpart of the matrix-core factorisation (v_mfma_f64_16x16x4_f64).
+//   ekf_factor_mfma_big_f32<128>  64 < k <= 128 in f32: four 32-wide blocks.
+//   ekf_panel_mfma_f64            the f64 gain / correction panel product.
+//   ekf_downdate_psym_f32         the unpipelined persistent symmetric P-GEMM: any k (windows beyond 128 columns), and the
+//                                 full-storage form (CSLAM_STORAGE=full) with mirror stores.
+// Earlier generations (a tile-per-workgroup P-GEMM, a P-GEMM pipelined across tiles only, workgroup-parallel and 2x2-blocked
+// factorisations, a triangular-solve gain kernel) were measured against these and removed; DESIGN.md 8 keeps the numbers.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -400,7 +403,6 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
     __shared__ T   sub[(3 + K) * LD]; // the rows of PHT that H touches: 0,1,2, then fx_o, fx_o+1 per observation
     __shared__ T   coef[(K / 2) * 10];
     __shared__ T   V[K];
-    __shared__ T   tvec[K];
     __shared__ int fxs[K / 2];
     __shared__ int sflg[2];
     const int      k   = 2 * a.m;
@@ -670,36 +672,6 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
         }
         stamp(2);
         T chk = (T)0;
-        if (a.dL != nullptr)
-        {
-            // Solve mode (ekf_gain_solve_f32 applies inv(L) by substitution): publish L and 1/diag, no inverse.
-            // L goes through the LDS area of G: column j, rows from the lanes that hold them.
-#pragma unroll
-            for (int j = 0; j < K; j++)
-            {
-                const bool onh = on_half(j);
-                if (j < 32)
-                {
-                    Gm[onh ? lc + j * LD : trash] = la0[j];
-                    chk                           = __builtin_fmaf(la0[j], (T)0, chk);
-                }
-                if (K == 64)
-                {
-                    Gm[onh ? 32 + lc + j * LD : trash] = la1[j];
-                    chk                                = __builtin_fmaf(la1[j], (T)0, chk);
-                }
-                chk = __builtin_fmaf(rdiag[j], (T)0, chk);
-            }
-            if (lane == 0)
-            {
-#pragma unroll
-                for (int j = 0; j < K; j++)
-                {
-                    tvec[j] = rdiag[j];
-                }
-            }
-        }
-        else
         {
         // ---- inv(L): R = I, then for every q: X[q][:] = R[q][:] / L[q][q], R -= L[:, q] X[q][:] ----
         // X[q][c] goes to Gm[q + c*LD] (the transposition for TEXTBOOK happens when G is read back); per-lane base
@@ -781,34 +753,6 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
             }
         }
         __syncthreads();
-    }
-    if (a.dL != nullptr)
-    {
-        // solve mode: L (K x K, column-major, zeros above the diagonal, identity padding) and 1/diag; zeros if flagged
-        constexpr int NE = (K * K + 255) / 256;
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            const int e = tid + it * 256;
-            const int r = e & (K - 1), c = e / K;
-            a.dL[e]     = (r >= c) ? Gm[r + c * LD] : (T)0;
-        }
-        if (tid < K)
-        {
-            a.dRdiag[tid] = zero ? (T)0 : tvec[tid];
-        }
-        stamp(9);
-        stamp(4);
-        if (tid == 0)
-        {
-            const int code = (sflg[0] ? kFlagLltFailed : 0) | (sflg[1] ? kFlagZeroed : 0);
-            a.flags[1]     = code;
-            if (code)
-            {
-                atomicOr(&a.flags[0], code);
-            }
-        }
-        return;
     }
     // outputs: G^T (what the gain kernel reads; the debug entry point transposes it back), t = G^T V, u = G t.
     // G[r][c]: REF_EXACT G = inv(L) = X, TEXTBOOK G = X^T
@@ -1806,833 +1750,6 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_big_f32(FactorArgs<float>
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2+K3 for 32 < k <= 64 in f32, blocked 2 x 2 with 32 x 32 blocks:
-//     S = [A11 .; A21 A22]    L11 = chol(A11)            X11 = inv(L11)      (one wave, a row per lane, v_readlane)
-//                             L21 = A21 * X11^T                               (MFMA 32x32x2, operands from LDS)
-//                             L22 = chol(A22 - L21*L21^T) X22 = inv(L22)
-//                             X21 = -X22 * (L21 * X11)                        inv(L) = [X11 0; X21 X22]
-// The serial chain is two 32-column factorisations instead of one 64-column one (the readlane chain grows with
-// K^2), and the 32^3 products cost 16 MFMAs each.  Everything after the workgroup-wide S build runs in wave 0,
-// so there are no barriers inside (one wave's LDS operations are ordered).  Padding rows/cols [k,64) = identity.
-// ------------------------------------------------------------------------------------------------
-template <int KB>
-__device__ inline bool chol_rows_readlane(float (&row)[KB], int lane)
-{
-    bool failed = false;
-#pragma unroll
-    for (int j = 0; j < KB; j++)
-    {
-        if (!failed)
-        {
-            const float dj = bcast(row[j], j);
-            if (dj <= 0.f)
-            {
-                failed = true;
-            }
-            else
-            {
-                const float sj = dsqrt(dj);
-                row[j]         = (lane == j) ? sj : row[j] / sj;
-#pragma unroll
-                for (int c = j + 1; c < KB; c++)
-                {
-                    row[c] -= row[j] * bcast(row[j], c);
-                }
-            }
-        }
-    }
-    return failed;
-}
-
-template <int KB>
-__device__ inline void inv_cols_readlane(const float (&row)[KB], float (&x)[KB], int lane)
-{
-#pragma unroll
-    for (int r = 0; r < KB; r++)
-    {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < r; q++)
-        {
-            s += bcast(row[q], r) * x[q];
-        }
-        x[r] = (((lane == r) ? 1.f : 0.f) - s) / bcast(row[r], r);
-    }
-}
-
-__global__ void __launch_bounds__(256) ekf_factor_blocked64_f32(FactorArgs<float> a, float* __restrict__ du)
-{
-    constexpr int K = 64, LD = K + 1, KB = 32, LT = KB + 1;
-    __shared__ float S[K * LD];  // S, then L (lower blocks) in place
-    __shared__ float G[K * LD];  // inv(L), then G in its final orientation
-    __shared__ float Tt[KB * LT]; // L21 * X11
-    __shared__ float coef[(K / 2) * 10];
-    __shared__ float V[K];
-    __shared__ float tvec[K];
-    __shared__ int   fxs[K / 2];
-    __shared__ int   sflg[2];
-    const int        k   = 2 * a.m;
-    const int        tid = threadIdx.x;
-
-    if (a.stamps && tid == 0)
-    {
-        a.stamps[0] = (long long)__builtin_readcyclecounter();
-    }
-    if (tid == 0)
-    {
-        sflg[0] = 0;
-        sflg[1] = 0;
-    }
-    if (tid < K)
-    {
-        V[tid] = 0.f;
-    }
-    __syncthreads();
-    for (int o = tid; o < a.m; o += 256)
-    {
-        observe_model<float>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
-        a.dV[2 * o]     = V[2 * o];
-        a.dV[2 * o + 1] = V[2 * o + 1];
-    }
-    if (a.stamps && tid == 0)
-    {
-        a.stamps[1] = (long long)__builtin_readcyclecounter();
-    }
-    __syncthreads();
-    {
-        constexpr int NE = (K * K) / 256;
-        const float   r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3];
-        float         ph[NE][5];
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            const int  e  = tid + it * 256;
-            const int  r  = e & (K - 1);
-            const int  c  = e / K;
-            const bool in = (r < k) && (c < k);
-            const int  rc = in ? r : 0, cc = in ? c : 0;
-            const int  fx = fxs[rc >> 1];
-            const float* p = a.PHT + (size_t)cc * a.ldw;
-            ph[it][0]     = p[0];
-            ph[it][1]     = p[1];
-            ph[it][2]     = p[2];
-            ph[it][3]     = p[fx];
-            ph[it][4]     = p[fx + 1];
-        }
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            const int e = tid + it * 256;
-            const int r = e & (K - 1);
-            const int c = e / K;
-            float     v;
-            if (r < k && c < k)
-            {
-                const int    ob = r >> 1, ra = r & 1;
-                const float* cf = &coef[ob * 10 + ra * 5];
-                float        sm = cf[0] * ph[it][0];
-                sm += cf[1] * ph[it][1];
-                sm += cf[2] * ph[it][2];
-                sm += cf[3] * ph[it][3];
-                sm += cf[4] * ph[it][4];
-                const float rv = ((ra + 2 * (c & 1)) == 0) ? r00 : (((ra + 2 * (c & 1)) == 1) ? r10 : (((ra + 2 * (c & 1)) == 2) ? r01 : r11));
-                v = sm + (((c >> 1) == ob) ? rv : 0.f);
-            }
-            else
-            {
-                v = (r == c) ? 1.f : 0.f;
-            }
-            S[r + c * LD] = v;
-        }
-    }
-    if (a.stamps && tid == 0)
-    {
-        a.stamps[2] = (long long)__builtin_readcyclecounter();
-    }
-    __syncthreads();
-    for (int e = tid; e < K * K; e += 256) // makeSymmetric (slam.h:776-779)
-    {
-        const int r = e & (K - 1);
-        const int c = e / K;
-        if (r > c)
-        {
-            const float v = (S[r + c * LD] + S[c + r * LD]) * 0.5f;
-            S[r + c * LD] = v;
-            S[c + r * LD] = v;
-        }
-        else if (r == c)
-        {
-            const float d = S[r + c * LD];
-            S[r + c * LD] = (d + d) * 0.5f;
-        }
-        G[r + c * LD] = 0.f;
-    }
-    __syncthreads();
-    for (int e = tid; e < K * K; e += 256)
-    {
-        const int r = e & (K - 1), c = e / K;
-        if (r < k && c < k)
-        {
-            a.dS[r + c * k] = S[r + c * LD];
-        }
-    }
-    __syncthreads();
-
-    if (a.stamps && tid == 0)
-    {
-        a.stamps[3] = (long long)__builtin_readcyclecounter();
-    }
-    if (tid < 64) // ------------------------------------------------ wave 0
-    {
-        const int lane = tid;
-        const int lj = lane & 31, lh = lane >> 5;
-        bool      failed = false;
-        float     row[KB], x[KB];
-        // ---- block (0,0): L11 and X11
-#pragma unroll
-        for (int c = 0; c < KB; c++)
-        {
-            row[c] = (lane < KB) ? S[lane + c * LD] : ((c == lane - KB) ? 1.f : 0.f);
-        }
-        failed = chol_rows_readlane<KB>(row, lane);
-        if (!failed)
-        {
-            inv_cols_readlane<KB>(row, x, lane);
-            if (lane < KB)
-            {
-#pragma unroll
-                for (int c = 0; c < KB; c++)
-                {
-                    S[lane + c * LD] = (c <= lane) ? row[c] : 0.f; // L11 (row = lane)
-                    G[c + lane * LD] = x[c];                       // X11[c][lane]: lane = column
-                }
-            }
-            if (a.stamps && tid == 0)
-        {
-            a.stamps[4] = (long long)__builtin_readcyclecounter();
-        }
-        // ---- L21 = A21 * X11^T : D[i][j] = sum_q X11[i][q] * A21[j][q]  (i = column of L21, j = row)
-            f32x16 acc = {0};
-#pragma unroll
-            for (int t = 0; t < KB / 2; t++)
-            {
-                const int   q  = 2 * t + lh;
-                const float av = G[lj + q * LD];        // X11[lj][q]
-                const float bv = S[(KB + lj) + q * LD]; // A21[lj][q]
-                acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                S[(KB + lj) + c * LD] = acc[r]; // L21[lj][c]
-            }
-            // ---- A22 <- A22 - L21 * L21^T
-            f32x16 acc2 = {0};
-#pragma unroll
-            for (int t = 0; t < KB / 2; t++)
-            {
-                const int   q  = 2 * t + lh;
-                const float lv = S[(KB + lj) + q * LD]; // L21[lj][q] serves as A[i=lj][q] and B[q][j=lj]
-                acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(lv, lv, acc2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                S[(KB + lj) + (KB + i) * LD] -= acc2[r]; // symmetric: element (j, i)
-            }
-            if (a.stamps && tid == 0)
-            {
-                a.stamps[5] = (long long)__builtin_readcyclecounter();
-            }
-            // ---- block (1,1): L22 and X22
-#pragma unroll
-            for (int c = 0; c < KB; c++)
-            {
-                row[c] = (lane < KB) ? S[(KB + lane) + (KB + c) * LD] : ((c == lane - KB) ? 1.f : 0.f);
-            }
-            failed = chol_rows_readlane<KB>(row, lane);
-        }
-        if (!failed)
-        {
-            inv_cols_readlane<KB>(row, x, lane);
-            if (lane < KB)
-            {
-#pragma unroll
-                for (int c = 0; c < KB; c++)
-                {
-                    S[(KB + lane) + (KB + c) * LD] = (c <= lane) ? row[c] : 0.f; // L22
-                    G[(KB + c) + (KB + lane) * LD] = x[c];                       // X22[c][lane]
-                }
-            }
-            if (a.stamps && tid == 0)
-            {
-                a.stamps[6] = (long long)__builtin_readcyclecounter();
-            }
-            // ---- T = L21 * X11 : D[i][j] = sum_q X11[q][i] * L21[j][q]  (i = column c of T, j = row r)
-            f32x16 acc = {0};
-#pragma unroll
-            for (int t = 0; t < KB / 2; t++)
-            {
-                const int   q  = 2 * t + lh;
-                const float av = G[q + lj * LD];        // X11[q][lj]
-                const float bv = S[(KB + lj) + q * LD]; // L21[lj][q]
-                acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                Tt[lj + c * LT] = acc[r]; // T[lj][c]
-            }
-            // ---- X21 = -X22 * T : D[i][j] = sum_q T[q][i] * X22[j][q]
-            f32x16 acc3 = {0};
-#pragma unroll
-            for (int t = 0; t < KB / 2; t++)
-            {
-                const int   q  = 2 * t + lh;
-                const float av = Tt[q + lj * LT];                  // T[q][lj]
-                const float bv = G[(KB + lj) + (KB + q) * LD];     // X22[lj][q]
-                acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc3, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                G[(KB + lj) + c * LD] = -acc3[r]; // X21[lj][c]
-            }
-        }
-        if (lane == 0)
-        {
-            sflg[0] = failed ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    if (a.stamps && tid == 0)
-    {
-        a.stamps[7] = (long long)__builtin_readcyclecounter();
-    }
-    const bool failed = sflg[0] != 0;
-    // finite check of inv(L) (slam.h:252-255)
-    if (!failed)
-    {
-        int bad = 0;
-        for (int e = tid; e < K * K; e += 256)
-        {
-            const int r = e & (K - 1), c = e / K;
-            if (r < k && c < k)
-            {
-                bad |= !dfinite(G[r + c * LD]);
-            }
-        }
-        if (bad)
-        {
-            atomicOr(&sflg[1], 1);
-        }
-    }
-    __syncthreads();
-    const bool zero = failed || (sflg[1] != 0);
-    for (int e = tid; e < K * K; e += 256)
-    {
-        const int rr = e & (K - 1), cc = e / K;
-        if (rr < k && cc < k)
-        {
-            const float g = zero ? 0.f : (a.textbook ? G[cc + rr * LD] : G[rr + cc * LD]);
-            a.dG[rr + cc * k]  = g;
-            a.dGt[cc + rr * k] = g;
-        }
-    }
-    {
-        const int o = tid >> 2, part = tid & 3;
-        float     s1 = 0.f;
-        if (!zero)
-        {
-            for (int q = part; q < K; q += 4)
-            {
-                const float g = a.textbook ? G[o + q * LD] : G[q + o * LD]; // G[q][o]
-                s1 += g * V[q];
-            }
-        }
-        s1 += __shfl_xor(s1, 1);
-        s1 += __shfl_xor(s1, 2);
-        if (part == 0)
-        {
-            if (o < k)
-            {
-                a.dt[o] = s1;
-            }
-            tvec[o] = (o < k) ? s1 : 0.f;
-        }
-        __syncthreads();
-        float s2 = 0.f;
-        if (!zero)
-        {
-            for (int q = part; q < K; q += 4)
-            {
-                const float g = a.textbook ? G[q + o * LD] : G[o + q * LD]; // G[o][q]
-                s2 += g * tvec[q];
-            }
-        }
-        s2 += __shfl_xor(s2, 1);
-        s2 += __shfl_xor(s2, 2);
-        if (part == 0 && o < k)
-        {
-            du[o] = s2;
-        }
-    }
-    if (a.stamps && tid == 0)
-    {
-        a.stamps[8] = (long long)__builtin_readcyclecounter();
-    }
-    if (tid == 0)
-    {
-        const int code = (failed ? kFlagLltFailed : 0) | ((!failed && sflg[1]) ? kFlagZeroed : 0);
-        a.flags[1]     = code;
-        if (code)
-        {
-            atomicOr(&a.flags[0], code);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2+K3, workgroup-parallel form for k <= K (K = 16, 32, 64, 128): threads = 4*K, thread = (row r, part p).
-// The matrix stays in LDS (leading dimension K+1).  Every length-j dot product of the column-by-column
-// Cholesky and of the forward substitution is split over the 4 lanes of a row (q = p, p+4, ...) and combined
-// with two __shfl_xor, so the serial chain per column is ~j/4 FMAs instead of j.  The Cholesky needs two
-// barriers per column (pivot, column publish); the inverse needs none (L is read-only by then, each row of
-// lanes owns one column of inv(L) in registers).  Same outputs as ekf_factor_small_kernel.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int K>
-__global__ void __launch_bounds__((4 * K < 64) ? 64 : 4 * K) ekf_factor_par_kernel(FactorArgs<T> a, T* __restrict__ du)
-{
-    constexpr int NT = (4 * K < 64) ? 64 : 4 * K;
-    constexpr int LD = K + 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T*   S    = reinterpret_cast<T*>(smem_raw); // K*LD : S, then L in place
-    T*   G    = S + K * LD;                     // K*LD : inv(L) / G
-    T*   coef = G + K * LD;                     // (K/2)*10
-    T*   V    = coef + (K / 2) * 10;            // K
-    T*   tvec = V + K;                          // K
-    T*   pivb = tvec + K;                       // 1 (+1 pad)
-    int* fxs  = reinterpret_cast<int*>(pivb + 2); // K/2
-    int* sflg = fxs + K / 2;                    // 2
-    const int k   = 2 * a.m;
-    const int tid = threadIdx.x;
-
-    if (tid == 0)
-    {
-        sflg[0] = 0;
-        sflg[1] = 0;
-    }
-    if (tid < K)
-    {
-        V[tid] = (T)0;
-    }
-    __syncthreads();
-    for (int o = tid; o < a.m; o += NT)
-    {
-        observe_model<T>(a.X, a.n, a.idf[o], a.Z[2 * o], a.Z[2 * o + 1], &coef[o * 10], &V[2 * o], &fxs[o]);
-        a.dV[2 * o]     = V[2 * o];
-        a.dV[2 * o + 1] = V[2 * o + 1];
-    }
-    __syncthreads();
-    // S = H*PHT + RR (slam.h:244), identity padding; all loads of a thread issued before the sums
-    {
-        constexpr int NE = (K * K + NT - 1) / NT;
-        const T       r00 = a.R[0], r10 = a.R[1], r01 = a.R[2], r11 = a.R[3];
-        T             ph[NE][5];
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            const int  e  = tid + it * NT;
-            const int  r  = e & (K - 1);
-            const int  c  = e / K;
-            const bool in = (e < K * K) && (r < k) && (c < k);
-            const int  rc = in ? r : 0, cc = in ? c : 0;
-            const int  fx = fxs[rc >> 1];
-            const T*   p  = a.PHT + (size_t)cc * a.ldw;
-            ph[it][0]     = p[0];
-            ph[it][1]     = p[1];
-            ph[it][2]     = p[2];
-            ph[it][3]     = p[fx];
-            ph[it][4]     = p[fx + 1];
-        }
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            const int e = tid + it * NT;
-            if (e < K * K)
-            {
-                const int r = e & (K - 1);
-                const int c = e / K;
-                T         v;
-                if (r < k && c < k)
-                {
-                    const int ob = r >> 1, ra = r & 1;
-                    const T*  cf = &coef[ob * 10 + ra * 5];
-                    T         sm = cf[0] * ph[it][0];
-                    sm += cf[1] * ph[it][1];
-                    sm += cf[2] * ph[it][2];
-                    sm += cf[3] * ph[it][3];
-                    sm += cf[4] * ph[it][4];
-                    const int ri = ra + 2 * (c & 1);
-                    const T   rv = (ri == 0) ? r00 : ((ri == 1) ? r10 : ((ri == 2) ? r01 : r11));
-                    v = sm + (((c >> 1) == ob) ? rv : (T)0);
-                }
-                else
-                {
-                    v = (r == c) ? (T)1 : (T)0;
-                }
-                S[r + c * LD] = v;
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < K * K; e += NT) // makeSymmetric (slam.h:776-779)
-    {
-        const int r = e & (K - 1);
-        const int c = e / K;
-        if (r > c)
-        {
-            T v           = (S[r + c * LD] + S[c + r * LD]) * (T)0.5;
-            S[r + c * LD] = v;
-            S[c + r * LD] = v;
-        }
-        else if (r == c)
-        {
-            T d           = S[r + c * LD];
-            S[r + c * LD] = (d + d) * (T)0.5;
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < K * K; e += NT)
-    {
-        const int r = e & (K - 1), c = e / K;
-        if (r < k && c < k)
-        {
-            a.dS[r + c * k] = S[r + c * LD];
-        }
-    }
-    __syncthreads();
-
-    // ---- lower Cholesky, column by column; thread = (row r, part p); a pivot <= 0 is the LLT failure (slam.h:421)
-    const int  r      = tid >> 2;
-    const int  part   = tid & 3;
-    const bool rowok  = (r < K);
-    bool       failed = false;
-    for (int j = 0; j < K; j++)
-    {
-        T dot = (T)0;
-        if (rowok)
-        {
-            for (int q = part; q < j; q += 4)
-            {
-                dot += S[r + q * LD] * S[j + q * LD];
-            }
-        }
-        dot += __shfl_xor(dot, 1);
-        dot += __shfl_xor(dot, 2);
-        const T sv = rowok ? (S[r + j * LD] - dot) : (T)0;
-        if (rowok && part == 0 && r == j)
-        {
-            pivb[0] = sv;
-        }
-        __syncthreads();
-        const T d = pivb[0];
-        if (d <= (T)0)
-        {
-            failed = true; // uniform: every thread read the same pivot
-            break;
-        }
-        const T sj = dsqrt(d);
-        if (rowok && part == 0 && r >= j)
-        {
-            S[r + j * LD] = (r == j) ? sj : sv / sj;
-        }
-        __syncthreads();
-    }
-    // ---- inv(L) by forward substitution: (row-of-lanes c, part p) owns x[q], q = p + 4i, of column c
-    bool bad = false;
-    if (!failed)
-    {
-        const int c = r;
-        T         x[K / 4 + 1];
-#pragma unroll
-        for (int i = 0; i < K / 4 + 1; i++)
-        {
-            x[i] = (T)0;
-        }
-#pragma unroll
-        for (int rr = 0; rr < K; rr++)
-        {
-            T sum = (T)0;
-#pragma unroll
-            for (int i = 0; i < (rr + 3) / 4; i++) // q = part + 4i < rr for the parts that have one; others add 0*...
-            {
-                const int q = part + 4 * i;
-                if (q < rr)
-                {
-                    sum += S[rr + q * LD] * x[i];
-                }
-            }
-            sum += __shfl_xor(sum, 1);
-            sum += __shfl_xor(sum, 2);
-            const T xr = (((c == rr) ? (T)1 : (T)0) - sum) / S[rr + rr * LD];
-            if (part == (rr & 3))
-            {
-                x[rr >> 2] = xr;
-            }
-            if (rowok && c < k && part == (rr & 3))
-            {
-                bad = bad || !dfinite(xr);
-            }
-        }
-        if (rowok)
-        {
-#pragma unroll
-            for (int i = 0; i < K / 4; i++)
-            {
-                G[(part + 4 * i) + c * LD] = x[i]; // inv(L)[q][c]
-            }
-        }
-    }
-    if (bad)
-    {
-        atomicOr(&sflg[1], 1);
-    }
-    __syncthreads();
-    const bool zero = failed || (sflg[1] != 0);
-    // outputs in the final orientation: REF_EXACT G = inv(L); TEXTBOOK G = inv(L)^T (quirk #1)
-    for (int e = tid; e < K * K; e += NT)
-    {
-        const int rr = e & (K - 1), cc = e / K;
-        if (rr < k && cc < k)
-        {
-            const T g = zero ? (T)0 : (a.textbook ? G[cc + rr * LD] : G[rr + cc * LD]);
-            a.dG[rr + cc * k]  = g;
-            a.dGt[cc + rr * k] = g;
-        }
-    }
-    // t = G^T V and u = G t, 4 lanes per output
-    {
-        const int o = tid >> 2;
-        T         s1 = (T)0;
-        if (o < K && !zero)
-        {
-            for (int q = part; q < K; q += 4)
-            {
-                const T g = a.textbook ? G[o + q * LD] : G[q + o * LD]; // G[q][o]
-                s1 += g * V[q];
-            }
-        }
-        s1 += __shfl_xor(s1, 1);
-        s1 += __shfl_xor(s1, 2);
-        if (part == 0 && o < K)
-        {
-            if (o < k)
-            {
-                a.dt[o] = s1;
-            }
-            tvec[o] = (o < k) ? s1 : (T)0;
-        }
-        __syncthreads();
-        T s2 = (T)0;
-        if (o < K && !zero)
-        {
-            for (int q = part; q < K; q += 4)
-            {
-                const T g = a.textbook ? G[q + o * LD] : G[o + q * LD]; // G[o][q]
-                s2 += g * tvec[q];
-            }
-        }
-        s2 += __shfl_xor(s2, 1);
-        s2 += __shfl_xor(s2, 2);
-        if (part == 0 && o < k)
-        {
-            du[o] = s2;
-        }
-    }
-    if (tid == 0)
-    {
-        const int code = (failed ? kFlagLltFailed : 0) | ((!failed && sflg[1]) ? kFlagZeroed : 0);
-        a.flags[1]     = code;
-        if (code)
-        {
-            atomicOr(&a.flags[0], code);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4 (f32), triangular-solve form for 16 < k <= 64: W1 = PHT * inv(L)^T (TEXTBOOK) or PHT * inv(L) (REF_EXACT,
-// slam.h:257 with the lower factor of slam.h:423) WITHOUT forming inv(L): one lane owns one row p of PHT (K values in
-// registers) and solves  w A = p  for a lower-triangular A by blocks of four columns, last block first.  The
-// multipliers are the same for every row, so they come from LDS as 16-byte broadcast reads (M[c + q*K] = A[q][c]),
-// two v_pk_fma_f32 per read.  REF_EXACT: A = L.  TEXTBOOK: w L^T = p is the same problem with every index reversed
-// (J L^T J is lower triangular), so the one code path serves both with a compile-time index map.
-// The factor kernel then stops after the Cholesky factorisation: the triangular inverse (13 k cycles) and the
-// G / G^T / t / u outputs (8 k) leave the serial chain; substitution is also the better conditioned way to apply a
-// triangular inverse.  X += W1 * t fused, t = inv(A)^T V' solved per wave from the factor in LDS (slam.h:258-259
-// regrouped: W V = W1 (inv(L) V) resp. W1 (inv(L)^T V)).  flags[1] != 0 (LLT failure / non-finite factor): W1 = 0,
-// X kept.  grid = ceil(n_pad / 256) workgroups of 4 waves (64 rows each); writes W1 columns [0, k8).
-// STATUS: correct (parity-green in both quirk modes) but NOT the shipped path: at N = 5000, k = 64 it takes 18 us
-// against 7.7 us for the MFMA product with the explicit inverse, which outweighs the 5 us the factor kernel saves.
-// Selected with CSLAM_TUNE_GAIN=1.
-// ------------------------------------------------------------------------------------------------
-template <int K, bool TEXTBOOK>
-__global__ void __launch_bounds__(256) ekf_gain_solve_f32(const float* __restrict__ PHT, int ldw, int n, int n_pad, int k,
-                                                          int k8, const float* __restrict__ Lg,
-                                                          const float* __restrict__ rdg, const float* __restrict__ V,
-                                                          const int* __restrict__ flags, float* __restrict__ W1, int ldo,
-                                                          float* __restrict__ X)
-{
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(16))) float M[K * K]; // M[c + q*K] = A[q][c]
-    __shared__ float rd[K];
-    __shared__ __attribute__((aligned(16))) float ts[4][K];
-    auto ix = [](int c) { return TEXTBOOK ? (K - 1 - c) : c; }; // solve index -> column of L / PHT / W1
-    const int  tid  = threadIdx.x;
-    const int  wave = tid >> 6;
-    const int  lane = tid & 63;
-    const int  row0 = blockIdx.x * 256 + tid;
-    const bool live = row0 < n_pad; // (the last workgroup may reach past the padded row count)
-    const int  row  = live ? row0 : 0;
-    const bool dead = flags[1] != 0;
-    // L (K x K, column-major, identity padding): REF_EXACT A[q][c] = L[q][c]; TEXTBOOK A[q][c] = L[K-1-c][K-1-q]
-    // (all loads of a thread first, then the LDS stores: one L2 round trip instead of sixteen)
-    {
-        constexpr int NE = K * K / 256;
-        float         lv[NE];
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            lv[it] = Lg[tid + it * 256];
-        }
-#pragma unroll
-        for (int it = 0; it < NE; it++)
-        {
-            const int e = tid + it * 256;
-            const int r = e & (K - 1), c = e / K; // Lg[e] = L[r][c]
-            if (TEXTBOOK)
-            {
-                M[(K - 1 - r) + (K - 1 - c) * K] = lv[it];
-            }
-            else
-            {
-                M[c + r * K] = lv[it];
-            }
-        }
-    }
-    if (tid < K)
-    {
-        rd[ix(tid)] = rdg[tid];
-    }
-    // this lane's row of PHT in solve order (columns >= k are padding: zero)
-    float p[K];
-#pragma unroll
-    for (int c = 0; c < K; c++)
-    {
-        const int  col = ix(c);
-        const float v  = PHT[(size_t)(col < k ? col : 0) * ldw + row];
-        p[c]           = (col < k) ? v : 0.f;
-    }
-    __syncthreads();
-    // ---- t = inv(A)^T v', once per wave: lane c holds element c; column `lane` of A in registers
-    {
-        float acol[K]; // A[q][lane]
-#pragma unroll
-        for (int q = 0; q < K; q++)
-        {
-            acol[q] = (lane < K) ? M[lane + q * K] : 0.f;
-        }
-        const int vi = ix(lane < K ? lane : 0);
-        float     v  = (lane < K && vi < k) ? V[vi] : 0.f;
-#pragma unroll
-        for (int c = K - 1; c >= 0; c--) // A^T t = v: t_c = v_c / A_cc, then v_r -= A[c][r] t_c for r < c
-        {
-            const float tc = bcast(v, c) * rd[c];
-            v              = (lane == c) ? tc : ((lane < c) ? __builtin_fmaf(-acol[c], tc, v) : v);
-        }
-        if (lane < K)
-        {
-            ts[wave][lane] = v;
-        }
-    }
-    // ---- w A = p, four columns at a time, last block first
-#pragma unroll
-    for (int b = K / 4 - 1; b >= 0; b--)
-    {
-        int mo = 0;
-        asm volatile("" : "+v"(mo)); // opaque (zero) offset per block: keeps the optimiser from hoisting every broadcast
-                                     // read of the solve to the top (an opaque POINTER would lose the LDS address space)
-        const float* Mb = M + mo;
-        f32x2 a01 = {p[4 * b], p[4 * b + 1]}, a23 = {p[4 * b + 2], p[4 * b + 3]};
-        // finished columns q > block: A[q][4b..4b+3] = M[4b.. + q*K]; the broadcast reads go out twelve at a time
-        // (left alone, the compiler waits for each one before its two FMAs: 500 exposed LDS round trips)
-        constexpr int QB = 12;
-#pragma unroll
-        for (int q0 = K - 1; q0 >= 4 * b + 4; q0 -= QB)
-        {
-            float4 l[QB];
-#pragma unroll
-            for (int j = 0; j < QB; j++)
-            {
-                const int q = q0 - j;
-                if (q >= 4 * b + 4)
-                {
-                    l[j] = *reinterpret_cast<const float4*>(&Mb[4 * b + q * K]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < QB; j++)
-            {
-                const int q = q0 - j;
-                if (q >= 4 * b + 4)
-                {
-                    const f32x2 wq = {p[q], p[q]};
-                    a01 -= wq * f32x2{l[j].x, l[j].y};
-                    a23 -= wq * f32x2{l[j].z, l[j].w};
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the 4 x 4 diagonal block, backward: rows 4b+1..4b+3 of A restricted to the block
-        const float4 r3 = *reinterpret_cast<const float4*>(&Mb[4 * b + (4 * b + 3) * K]); // A[4b+3][4b..4b+3]
-        const float4 r2 = *reinterpret_cast<const float4*>(&Mb[4 * b + (4 * b + 2) * K]);
-        const float4 r1 = *reinterpret_cast<const float4*>(&Mb[4 * b + (4 * b + 1) * K]);
-        const float  w3 = a23[1] * rd[4 * b + 3];
-        const float  w2 = (a23[0] - r3.z * w3) * rd[4 * b + 2];
-        const float  w1 = (a01[1] - r3.y * w3 - r2.y * w2) * rd[4 * b + 1];
-        const float  w0 = (a01[0] - r3.x * w3 - r2.x * w2 - r1.x * w1) * rd[4 * b];
-        p[4 * b]        = w0;
-        p[4 * b + 1]    = w1;
-        p[4 * b + 2]    = w2;
-        p[4 * b + 3]    = w3;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- outputs
-    float xs = 0.f;
-#pragma unroll
-    for (int c = 0; c < K; c++)
-    {
-        const int   col = ix(c);
-        const float w   = dead ? 0.f : p[c];
-        if (col < k8 && live)
-        {
-            W1[(size_t)col * ldo + row] = (col < k) ? w : 0.f;
-        }
-        xs = __builtin_fmaf(w, ts[wave][c], xs);
-    }
-    if (live && row < n && !dead)
-    {
-        X[row] += xs;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K4 (f32) on MFMA: W1 = PHT * G (slam.h:257), X += PHT * u with u = G*(G^T V) (slam.h:258-259 regrouped).
 // Tile = 32 rows x 32 columns per wave.  D[i][j]: i <-> output column, j <-> row (contiguous across lanes).
 //   A[i = lane&31][kq = lane>>5] = G[q0+kq][c0+i]   (read from Gt, contiguous across lanes)
@@ -2971,139 +2088,6 @@ __global__ void __launch_bounds__(64) ekf_panel_mfma_f64(const double* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5 (f32), version 2.  Same tiling and MFMA mapping as ekf_downdate_f32; differences:
-//   * the 128x128 P tile (16 x 16-byte loads per lane) is requested right after the first W1 panel and
-//     consumed only in the epilogue, so its HBM latency hides behind the MFMA loop.  The panel loads are
-//     issued BEFORE the P loads: vmcnt retires in order, so the wait for the panel leaves the 16 younger
-//     P loads in flight;
-//   * the k loop has a compile-time trip count per chunk (LDS rows beyond k are zero) and is fully unrolled.
-// KC = k-chunk staged in LDS: 2 * KC * 128 * 4 B (KC = 32 -> 32 KiB).
-// ------------------------------------------------------------------------------------------------
-template <int KC, bool NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_downdate2_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1,
-                                                             int ldw, int k, int tiles)
-{
-    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
-    float* sB = s_pan;            // rows of the tile
-    float* sA = s_pan + KC * 128; // columns of the tile
-
-    const int tid  = threadIdx.x;
-    const int wave = tid >> 6;
-    const int lane = tid & 63;
-    const int lj   = lane & 31;
-    const int lh   = lane >> 5;
-    const int tj   = blockIdx.x / tiles;
-    const int ti   = blockIdx.x % tiles;
-    const int row0 = ti * 128;
-    const int col0 = tj * 128;
-
-    constexpr int NLD = (KC * 32) / 256; // float4 per thread per panel
-    float4        stB[NLD], stA[NLD];
-
-    // ---- first panel chunk: issue its loads
-#pragma unroll
-    for (int it = 0; it < NLD; it++)
-    {
-        const int id = tid + it * 256;
-        const int kk = id >> 5;
-        const int r4 = (id & 31) * 4;
-        if (kk < k)
-        {
-            const float* w = W1 + (size_t)kk * ldw;
-            stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
-            stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
-        }
-        else
-        {
-            stB[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            stA[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    // ---- then the P tile (younger loads: stay in flight across the panel wait)
-    float4 pv[16];
-    float* pbase = P + (size_t)(col0 + wave * 32 + 4 * lh) * ldp + row0 + 4 * lj;
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-    {
-        const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-        if (NT)
-        {
-            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-            pv[r]         = make_float4(t[0], t[1], t[2], t[3]);
-        }
-        else
-        {
-            pv[r] = *reinterpret_cast<const float4*>(src);
-        }
-    }
-
-    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-
-    for (int k0 = 0; k0 < k; k0 += KC)
-    {
-        if (k0 > 0)
-        {
-            __syncthreads(); // everyone is done reading the previous chunk
-#pragma unroll
-            for (int it = 0; it < NLD; it++)
-            {
-                const int id = tid + it * 256;
-                const int kk = k0 + (id >> 5);
-                const int r4 = (id & 31) * 4;
-                if (kk < k)
-                {
-                    const float* w = W1 + (size_t)kk * ldw;
-                    stB[it]        = *reinterpret_cast<const float4*>(w + row0 + r4);
-                    stA[it]        = *reinterpret_cast<const float4*>(w + col0 + r4);
-                }
-                else
-                {
-                    stB[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    stA[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NLD; it++)
-        {
-            const int id = tid + it * 256;
-            *reinterpret_cast<float4*>(&sB[id * 4]) = stB[it];
-            *reinterpret_cast<float4*>(&sA[id * 4]) = stA[it];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 2)
-        {
-            const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + lh) * 128 + 4 * lj]);
-            const float  a = sA[(kk + lh) * 128 + wave * 32 + lj];
-            acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
-            acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
-            acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
-            acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-    {
-        float4 v = pv[r];
-        v.x -= acc0[r];
-        v.y -= acc1[r];
-        v.z -= acc2[r];
-        v.w -= acc3[r];
-        float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-        if (NT)
-        {
-            const f32x4 t = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
-        }
-        else
-        {
-            *reinterpret_cast<float4*>(dst) = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K5 (f32), persistent symmetric form -- the shipped P-GEMM.
 //   * symmetric: only tiles with ti >= tj are computed (half the MFMA work, half the P reads); the result of
 //     an off-diagonal tile is stored in place and (full storage only) transposed into the mirror tile: for MFMA
@@ -3276,259 +2260,6 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5 (f32), persistent symmetric form, software-pipelined across tiles (k8 <= 64: one panel chunk per tile).
-// Same tiling, MFMA mapping and register plan as ekf_downdate_psym_f32; what changes is the ORDER of the
-// memory operations, so that nothing ever waits for a store:
-//     loop over this workgroup's tiles:
-//        s_waitcnt vmcnt(#stores of the previous tile)   -> the panel DMA of THIS tile (issued before those
-//        s_barrier                                           stores) has landed; the stores keep draining
-//        request the NEXT tile's P values (16 loads/lane, second register set)
-//        MFMA loop over the panels in LDS
-//        s_barrier                                        -> every wave is done reading the panels
-//        LDS-DMA of the NEXT tile's panels                -> lands while the epilogue runs
-//        epilogue: P -= acc, 16 stores (+16 mirror stores under full storage)
-// vmcnt retires in order, so "all but the N youngest" with N = the stores issued after the DMA is exactly
-// "the DMA is complete".  __syncthreads() is not used in the loop: its fence would wait for vmcnt(0).
-// ------------------------------------------------------------------------------------------------
-template <bool NT, bool MIRROR>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8, int tiles,
-                       int ntiles, int* __restrict__ ticket, int* __restrict__ ticket_reset, int stagger_mode,
-                       int stagger_cycles, unsigned long long* __restrict__ hwids)
-{
-    constexpr int KC = 64;
-    __shared__ __attribute__((aligned(16))) float s_pan[2 * KC * 128];
-    __shared__ int s_next[2];
-    float* sB = s_pan;            // rows of the tile   [kk][128]
-    float* sA = s_pan + KC * 128; // columns of the tile [kk][128]
-
-    const int tid  = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int lj   = lane & 31;
-    const int lh   = lane >> 5;
-    const int G    = gridDim.x;
-
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void*       lptr_t;
-
-    // ticket t -> tile (x = tile row, y = tile column), x >= y, column after column:
-    // column c starts at f(c) = c*tiles - c(c-1)/2
-    auto tile_of = [&](int t) -> int2 {
-        const float b = 2.0f * tiles + 1.0f;
-        int         c = (int)((b - sqrtf(fmaxf(b * b - 8.0f * (float)t, 0.0f))) * 0.5f);
-        c             = min(max(c, 0), tiles - 1);
-        auto f        = [&](int cc) { return cc * tiles - ((cc * (cc - 1)) >> 1); };
-        while (c + 1 < tiles && f(c + 1) <= t)
-        {
-            c++;
-        }
-        while (c > 0 && f(c) > t)
-        {
-            c--;
-        }
-        return make_int2(c + (t - f(c)), c);
-    };
-    auto tile_base = [&](int2 t) -> float* {
-        return P + (size_t)(t.y * 128 + wave * 32 + 4 * lh) * ldp + t.x * 128 + 4 * lj;
-    };
-    auto load_tile = [&](float* pbase, f32x4 (&pv)[16]) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            const float* src = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-            if (NT)
-            {
-                pv[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-            }
-            else
-            {
-                pv[r] = *reinterpret_cast<const f32x4*>(src);
-            }
-        }
-    };
-    auto dma_panels = [&](int2 t) {
-        const int row0 = t.x * 128, col0 = t.y * 128;
-#pragma unroll
-        for (int it = 0; it < KC / 8; it++)
-        {
-            const int kkb = it * 8 + wave * 2;
-            if (kkb < k8)
-            {
-                const float* w = W1 + (size_t)(kkb + lh) * ldw + 4 * lj;
-                __builtin_amdgcn_global_load_lds((gptr_t)(w + row0), (lptr_t)(sB + kkb * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(w + col0), (lptr_t)(sA + kkb * 128), 16, 0, 0);
-            }
-        }
-    };
-    // FIRST: the first tile of this workgroup (its DMA is the youngest memory operation: wait for all);
-    // otherwise at least 16 stores were issued after the DMA that fed this tile (32 for a mirrored tile:
-    // waiting down to 16 then also retires the older half of those, which is harmless).
-    // The waits are the s_waitcnt builtin, not inline asm, so that the compiler's own wait-count pass sees
-    // them and does not add a vmcnt(0) in front of the first LDS read.
-    // gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
-    // Tiles are handed out dynamically: the first two of a workgroup are blockIdx.x and blockIdx.x + G, every
-    // later one comes from an atomic ticket counter.  (Measured with s_memrealtime: the second workgroup of each
-    // CU starts about 6 us after the first and runs about 30 % slower per tile -- the older waves win the
-    // arbitration -- so a static split left half of the chip idle for the last 20 us of the launch.)
-    // The ticket for the tile after `nxt` is requested before the MFMA loop by one lane, published through LDS
-    // behind the barrier that follows the loop, and returned to the caller.
-    auto process = [&](auto FIRST, int2 cur, f32x4 (&pv)[16], bool have_next, int2 nxt, f32x4 (&pn)[16]) -> int {
-        if (decltype(FIRST)::value)
-        {
-            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-        }
-        else
-        {
-            __builtin_amdgcn_s_waitcnt(0x4F70); // vmcnt(16)
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (have_next)
-        {
-            load_tile(tile_base(nxt), pn);
-        }
-        // the ticket request is inline asm so that the compiler does not wait for its return value here (it
-        // would: a returning atomic inside a divergent branch is waited for at the join); it is collected after
-        // the MFMA loop behind an explicit vmcnt(0)
-        int tk_raw = 0;
-        if (have_next && tid == 0)
-        {
-            const int zero = 0, one = 1;
-            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk_raw) : "v"(zero), "v"(one), "s"(ticket) : "memory");
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-        for (int kk = 0; kk < k8; kk += 8)
-        {
-#pragma unroll
-            for (int t = 0; t < 8; t += 2)
-            {
-                const float4 b = *reinterpret_cast<const float4*>(&sB[(kk + t + lh) * 128 + 4 * lj]);
-                const float  a = sA[(kk + t + lh) * 128 + wave * 32 + lj];
-                acc0           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
-                acc1           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
-                acc2           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc2, 0, 0, 0);
-                acc3           = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc3, 0, 0, 0);
-            }
-        }
-        // every wave has its operands in registers: the panels may be overwritten
-        if (tid == 0)
-        {
-            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the ticket has returned
-            asm volatile("" : "+v"(tk_raw));
-            s_next[0] = have_next ? 2 * G + tk_raw : ntiles;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): every LDS read (and the ticket write) of this wave is done
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int nn = __builtin_amdgcn_readfirstlane(s_next[0]);
-        if (have_next)
-        {
-            dma_panels(nxt);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float* pbase = tile_base(cur);
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            pv[r][0] -= acc0[r];
-            pv[r][1] -= acc1[r];
-            pv[r][2] -= acc2[r];
-            pv[r][3] -= acc3[r];
-            float* dst = pbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldp;
-            if (NT)
-            {
-                __builtin_nontemporal_store(pv[r], reinterpret_cast<f32x4*>(dst));
-            }
-            else
-            {
-                *reinterpret_cast<f32x4*>(dst) = pv[r];
-            }
-        }
-        if (MIRROR && cur.x != cur.y)
-        {
-            float* mbase = P + (size_t)(cur.x * 128 + 4 * lj) * ldp + cur.y * 128 + wave * 32 + 4 * lh;
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-            {
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                {
-                    const f32x4 m = {pv[4 * g + 0][b], pv[4 * g + 1][b], pv[4 * g + 2][b], pv[4 * g + 3][b]};
-                    *reinterpret_cast<f32x4*>(mbase + (size_t)b * ldp + 8 * g) = m;
-                }
-            }
-        }
-        return nn;
-    };
-
-    int t = blockIdx.x;
-    if (t == 0 && tid == 0)
-    {
-        *ticket_reset = 0; // the counter the NEXT launch on this stream will use
-    }
-    if (t >= ntiles)
-    {
-        return;
-    }
-    f32x4 pvA[16], pvB[16];
-    int2  cur = tile_of(t);
-    load_tile(tile_base(cur), pvA);
-    asm volatile("" ::: "memory"); // keep the requests here (their values are first used in the epilogue)
-    dma_panels(cur);
-    if (hwids != nullptr && tid == 0)
-    {
-        // diagnostics: HW_ID (hwreg 4) and XCC_ID (hwreg 20) of this workgroup's first wave
-        hwids[4 * blockIdx.x]     = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        hwids[4 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        hwids[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(); // 100 MHz, chip-wide
-    }
-    // Phase stagger: two workgroups share a CU and start together; left alone they run their MFMA loops at the
-    // same time (sharing the matrix pipe) and their memory phases at the same time (leaving it idle).  Delaying
-    // one of the two by about half a tile period makes them alternate.
-    const bool late = stagger_mode == 1 ? (blockIdx.x >= (unsigned)(G / 2))
-                    : stagger_mode == 2 ? (((blockIdx.x >> 3) & 1) != 0)
-                    : stagger_mode == 3 ? (((blockIdx.x >> 8) & 1) != 0)
-                                        : false;
-    if (late)
-    {
-        const long long t0 = (long long)__builtin_readcyclecounter();
-        while ((long long)__builtin_readcyclecounter() - t0 < stagger_cycles)
-        {
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    int  tn  = t + G;
-    bool hn  = tn < ntiles;
-    int2 nxt = hn ? tile_of(tn) : cur;
-    int  nn  = process(std::true_type{}, cur, pvA, hn, nxt, pvB);
-    while (hn)
-    {
-        cur = nxt;
-        tn  = nn;
-        hn  = tn < ntiles;
-        nxt = hn ? tile_of(tn) : cur;
-        nn  = process(std::false_type{}, cur, pvB, hn, nxt, pvA);
-        if (!hn)
-        {
-            break;
-        }
-        cur = nxt;
-        tn  = nn;
-        hn  = tn < ntiles;
-        nxt = hn ? tile_of(tn) : cur;
-        nn  = process(std::false_type{}, cur, pvA, hn, nxt, pvB);
-    }
-    if (hwids != nullptr && tid == 0)
-    {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        hwids[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K5 (f32), block-lower storage, k8 <= 64: the P-GEMM with every memory operation issued from INSIDE the MFMA
 // loop.  A pure read-modify-write of the same 3160 tiles (tools/probes/tile_rmw_probe.hip) takes 63 us; the
 // kernels above take 87-94 us because a wave's memory traffic comes in bursts between its MFMA loops (16 loads,
@@ -3546,7 +2277,7 @@ ekf_downdate_psym3_f32(float* __restrict__ P, int ldp, const float* __restrict__
 // so every chunk is 32 deep and the MFMA loops have fixed trip counts.
 // vmcnt retires in order: "all but the 24 youngest" at the top of chunk 1 = the DMA issued at the top of chunk 0
 // has landed (16 stores + 8 loads were issued after it; 8 for a workgroup's first tile).
-// Tile hand-out by atomic ticket (see psym3); a ticket requested at the top of tile i is collected at the top of
+// Tile hand-out by atomic ticket; a ticket requested at the top of tile i is collected at the top of
 // tile i+1, its tile looked up, published through LDS at the top of chunk 1 of tile i+1 and consumed there.
 // ------------------------------------------------------------------------------------------------
 // NTMODE: 0 ordinary accesses, 1 non-temporal loads and stores, 2 loads only, 3 stores only,

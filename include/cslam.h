@@ -198,7 +198,8 @@ int cslam_pf_observe_heading(cslam_pf_t h, double phi, int use_heading);
 
 /* Replaces PF::sampleProposal(particle, Z, idf, R) for every owned particle -- slam.h:881-884,
  * PF.cpp:502-544 (computeJacobians PF.cpp:70-135, likelihood 343-359, gaussEvaluate 279-317).
- * normals: 3 x n_particles scalars (host), the N(0,1) draws slam.h:753-764 would make.
+ * normals: 3 * n_particles scalars (host), the N(0,1) draws slam.h:753-764 would make, COMPONENT-major:
+ * normals[e * n_particles + p] is draw e (0..2) of particle p (i.e. an n_particles x 3 column-major matrix).
  * Like every per-particle call of this section, it consumes its host arrays before it returns but does
  * not wait for the device: the work is ordered on the handle's stream, and cslam_pf_synchronize() (or
  * any call that returns data to the host) waits for it. */

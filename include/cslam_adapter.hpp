@@ -268,7 +268,22 @@ class HipPF : public PF
     void sampleProposalAll(const Eigen::MatrixXf& Z, const Eigen::VectorXi& idf, const Eigen::MatrixXf& R,
                            const Eigen::MatrixXf& normals)
     {
-        report(cslam_pf_sample_proposal(h_, Z.data(), static_cast<int>(Z.cols()), idf.data(), R.data(), normals.data()),
+        // the engine wants the draws component-major (normals[e * numParticles + p], one coalesced load per component);
+        // an Eigen 3 x numParticles matrix is particle-major
+        if (normals.rows() != 3 || normals.cols() != np_)
+        {
+            std::cout << "HipPF::sampleProposal: normals must be 3 x " << np_ << "\t" << "sampleProposal" << std::endl;
+            return;
+        }
+        std::vector<float> nrm(static_cast<size_t>(3) * static_cast<size_t>(np_));
+        for (int p = 0; p < np_; p++)
+        {
+            for (int e = 0; e < 3; e++)
+            {
+                nrm[static_cast<size_t>(e) * static_cast<size_t>(np_) + static_cast<size_t>(p)] = normals(e, p);
+            }
+        }
+        report(cslam_pf_sample_proposal(h_, Z.data(), static_cast<int>(Z.cols()), idf.data(), R.data(), nrm.data()),
                "HipPF::sampleProposal"); // PF.cpp:502-544
     }
     void featureUpdateAll(const Eigen::MatrixXf& Z, const Eigen::VectorXi& idf, const Eigen::MatrixXf& R)

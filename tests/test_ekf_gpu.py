@@ -865,3 +865,71 @@ def test_per_xcd_tile_queues_change_nothing_but_the_order(gpu_required, monkeypa
         X0, P0 = run(0, defer)
         X1, P1 = run(1, defer)
         assert np.array_equal(X0, X1) and np.array_equal(P0, P1), defer
+
+
+SWITCHES = [
+    {"CSLAM_STORAGE": "full"},            # both triangles of P kept (mirror stores in the P-GEMM)
+    {"CSLAM_SEQ_DEFER": "0"},             # sequential update sweeps P once per observation
+    {"CSLAM_FUSE_F64": "0"},              # f64: a held predict gets its own launch
+    {"CSLAM_FUSE_PREDICT": "0"},          # every predict / heading launched at once
+    {"CSLAM_GATHER_WIDE": "0"},           # a 64-column pending panel goes through the separate correction kernel
+    {"CSLAM_PSYM_NT": "1"},               # non-temporal P accesses in the P-GEMM
+    {"CSLAM_PSYM_NT": "0"},
+    {"CSLAM_PIPELINE": "1"},              # the two-stream engine
+    {"CSLAM_PIPELINE": "1", "CSLAM_PGEMM_SPARE": "64"},
+    {"CSLAM_XCD_QUEUES": "1"},
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_every_engine_switch_gives_the_same_filter(gpu_required, monkeypatch, env, dtype):
+    """Every environment switch that selects a kernel or a schedule (read at cslam_ekf_create) runs a mixed sequence --
+    fused predict + batch update on the matrix-core kernels (k = 48), a 128-column deferral window, heading columns,
+    a sequential update, augment, a batch beyond the tuned shapes (k = 140: general factor / gain kernels, the
+    unpipelined P-GEMM) -- against the oracle, at the tolerances of the default engine."""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    N, extra = 330, 2
+    eng, orc, hi = _pair(N, dtype, TEXTBOOK, seed=808, extra=extra, corr=0.1)
+    eng.set_sync_mode(False)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    rng = np.random.default_rng(99)
+
+    def both(fn):
+        for s in (eng, orc, hi):
+            fn(s)
+
+    def upd(m, batch, seed):
+        idf = (rng.permutation(N)[:m] + 1).astype(np.int32)
+        Z = make_obs(orc.x(), idf, dtype, seed=seed)
+        eng.update(Z, R, idf, batch)
+        orc.update(Z, R, idf, batch)
+        hi.update(Z.astype(np.float64), R.astype(np.float64), idf, batch)
+
+    eng.set_deferred(128)
+    for step in range(4):                       # two windows of two k = 48 updates, predict fused
+        both(lambda s: s.predict(83.33, 0.02 * step, Q, 73.0, 0.01))
+        upd(24, True, step)
+    both(lambda s: s.predict(83.33, -0.03, Q, 73.0, 0.01))
+    both(lambda s: s.observe_heading(float(hi.x()[2]) + 1e-4, True))
+    upd(24, True, 10)                           # heading column + panel in one window
+    eng.set_deferred(0)
+    both(lambda s: s.predict(83.33, 0.01, Q, 73.0, 0.01))
+    upd(5, False, 11)                           # sequential: five rank-2 updates, one P-GEMM (or five)
+    Zn = np.array([[310.0], [0.4]], dtype=dtype)
+    eng.augment(Zn, R)
+    orc.augment(Zn, R)
+    hi.augment(Zn.astype(np.float64), R.astype(np.float64))
+    upd(70, True, 12)                           # k = 140: beyond every tuned shape
+    upd(3, True, 13)                            # k = 6: the one-wave factor kernel
+    assert eng.factor_status() == 0
+    X, P = eng.get_state()
+    dt = np.dtype(dtype)
+    assert_close("switch X", X, orc.x(), 4 * X_RTOL[dt], hi.x(), fair=8.0)
+    assert_close("switch P", P, orc.p(), 4 * P_RTOL[dt], hi.p(), fair=8.0)
+    M = P.copy()
+    M[:3, :3] = 0
+    assert np.array_equal(M, M.T)
+    eng.close()
