@@ -931,5 +931,9 @@ def test_every_engine_switch_gives_the_same_filter(gpu_required, monkeypatch, en
     assert_close("switch P", P, orc.p(), 4 * P_RTOL[dt], hi.p(), fair=8.0)
     M = P.copy()
     M[:3, :3] = 0
+    # (the augmented feature's own 2 x 2 block is the dense Gv Pvv Gv^T + Gz R Gz^T of EKF.cpp:74: symmetric to rounding,
+    # as in the reference, where both triangles are stored)
+    nf_new = 3 + 2 * N
+    M[nf_new:nf_new + 2, nf_new:nf_new + 2] = 0
     assert np.array_equal(M, M.T)
     eng.close()
