@@ -573,7 +573,7 @@ def ref_exact_healthy(args, torch, N, dtype):
     from conan_slam_amd import EKF, Q_REF_EXACT
     from conan_slam_amd.synth import Workload
 
-    n_w, n_t = 10, 100
+    n_w, n_t = 10, 60  # (the reference's gain keeps this map healthy for ~100 updates: the oracle's first LLT failure is at step 105)
     m = args.obs
     w = Workload(N, m, dtype, seed=0, corr=0.1)
     eng = EKF(N, dtype=dtype, quirks=Q_REF_EXACT, sync_mode=False)

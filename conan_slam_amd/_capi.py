@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcslam_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "cslam.h")
 
 OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = 0, 1, 2, 3, 4, 5
-FACTOR_OK, FACTOR_FALLBACK, FACTOR_ZEROED, FACTOR_SKIPPED, FACTOR_BAD_IDF = 0, 1, 2, 4, 8
+FACTOR_OK, FACTOR_FALLBACK, FACTOR_ZEROED, FACTOR_SKIPPED, FACTOR_BAD_IDF, FACTOR_INTERNAL = 0, 1, 2, 4, 8, 16
 F32, F64 = 0, 1
 Q_LOWER_CHOL_GAIN, Q_PREDICT_NM4, Q_REF_EXACT, Q_TEXTBOOK = 1, 2, 3, 0
 STAGE_GATHER, STAGE_FACTOR, STAGE_GAIN, STAGE_DOWNDATE, N_STAGES = 0, 1, 2, 3, 4

@@ -27,6 +27,7 @@
 #include "cslam_common.hpp"
 #include "ekf_kernels.hpp"
 #include "ekf_kernels_fast.hpp"
+#include "ekf_lookahead.hpp"
 #include "ekf_pgemm_limbs.hpp"
 #include "ekf_pose_kernels.hpp"
 #include "host_linalg.hpp"
@@ -59,6 +60,7 @@ struct EkfBase
     int         pgemm_spare   = 16; // pipelined: workgroups the persistent P-GEMM grid leaves out (env CSLAM_PGEMM_SPARE)
     int         gather_corr_wide = 1; // a pending batch panel (<= 64 columns) corrected for inside the gather kernel (env CSLAM_GATHER_WIDE)
     int         pgemm_wgs     = 0;  // > 0: cap on the persistent P-GEMM grid (cslam_ekf_set_pgemm_workgroups: co-running instances)
+    int         lookahead     = -1; // look-ahead windows (ekf_lookahead.hpp): -1 where they pay, env CSLAM_LOOKAHEAD=1 / 0 forces
     hipStream_t stream   = nullptr; // A: everything except the P-GEMM
     hipStream_t stream_b = nullptr; // B: the P-GEMM (== stream when not pipelined)
 
@@ -81,6 +83,7 @@ struct EkfBase
     virtual int resolve_predict()                                                              = 0;
     virtual void set_fuse_predict(int on)                                                      = 0;
     virtual int sync_all()                                                                     = 0;
+    virtual int la_drain()                                                                     = 0;
 };
 
 template <typename T>
@@ -179,6 +182,13 @@ struct Ekf : EkfBase
         {
             (void)hipStreamSynchronize(stream_b);
         }
+        if (stream_f)
+        {
+            (void)hipStreamSynchronize(stream_f);
+            (void)hipEventDestroy(ev_fb);
+            (void)hipStreamDestroy(stream_f);
+        }
+        la_free();
         if (ev_a2b)
         {
             (void)hipEventDestroy(ev_a2b);
@@ -447,6 +457,10 @@ struct Ekf : EkfBase
         {
             CSLAM_HIP_TRY(hipStreamSynchronize(stream_b));
         }
+        if (stream_f)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream_f));
+        }
         inflight_mask = 0;
         return CSLAM_OK;
     }
@@ -632,7 +646,15 @@ struct Ekf : EkfBase
             return CSLAM_OK;
         }
         int newm = std::max(m, 2 * mcap);
+        if (int rc = la_drain()) // (queued updates read the ring that is about to move)
+        {
+            return rc;
+        }
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+        if (stream_f)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream_f));
+        }
         if (hStage)
         {
             (void)hipHostFree(hStage);
@@ -641,7 +663,9 @@ struct Ekf : EkfBase
         (void)hipFree(dStage);
         dStage = nullptr;
         CSLAM_HIP_TRY(hipHostMalloc(&hStage, slot_bytes(newm) * kStagingSlots, hipHostMallocDefault));
-        CSLAM_HIP_TRY(hipMalloc(&dStage, slot_bytes(newm)));
+        // (a device slot per host slot: queued look-ahead updates read their inputs up to two calls later; a slot comes round
+        // again kStagingSlots calls later, stream-ordered behind every kernel that read it)
+        CSLAM_HIP_TRY(hipMalloc(&dStage, slot_bytes(newm) * kStagingSlots));
         mcap = newm;
         return CSLAM_OK;
     }
@@ -669,10 +693,11 @@ struct Ekf : EkfBase
         size_t         zb = (size_t)m * 2 * sizeof(T);
         memcpy(hs, Z, zb);
         memcpy(hs + zb, idf, (size_t)m * sizeof(int));
-        CSLAM_HIP_TRY(hipMemcpyAsync(dStage, hs, zb + (size_t)m * sizeof(int), hipMemcpyHostToDevice, stream));
+        unsigned char* ds = static_cast<unsigned char*>(dStage) + slot_bytes(mcap) * slot;
+        CSLAM_HIP_TRY(hipMemcpyAsync(ds, hs, zb + (size_t)m * sizeof(int), hipMemcpyHostToDevice, stream));
         CSLAM_HIP_TRY(hipEventRecord(stage_ev[slot], stream));
-        *dZ   = static_cast<const T*>(dStage);
-        *dIdf = reinterpret_cast<const int*>(static_cast<unsigned char*>(dStage) + zb);
+        *dZ   = reinterpret_cast<const T*>(ds);
+        *dIdf = reinterpret_cast<const int*>(ds + zb);
         return CSLAM_OK;
     }
 
@@ -841,6 +866,10 @@ struct Ekf : EkfBase
     }
     int set_profiling(int on) override
     {
+        if (int rc = la_drain())
+        {
+            return rc;
+        }
         if (int rc = sync_all())
         {
             return rc;
@@ -855,6 +884,10 @@ struct Ekf : EkfBase
         if (!ms || !launches)
         {
             return fail(CSLAM_ERR_BAD_ARG, "get_stage_times: null");
+        }
+        if (int rc = la_drain())
+        {
+            return rc;
         }
         if (int rc = sync_all())
         {
@@ -983,7 +1016,11 @@ struct Ekf : EkfBase
     // append one control step (predict and / or heading) to the pose queue
     int queue_step(const PredictArgs<T>& p, const HeadingArgs<T>& hd)
     {
-        int rc = CSLAM_OK;
+        int rc = la_drain(); // (queued look-ahead updates come before this control step)
+        if (rc)
+        {
+            return rc;
+        }
         if (seq.count == kPoseSeqMax && (rc = launch_pose_queue()))
         {
             return rc;
@@ -1041,7 +1078,11 @@ struct Ekf : EkfBase
     // everything queued (and the held predict) runs now
     int resolve_predict() override
     {
-        int rc = CSLAM_OK;
+        int rc = la_drain();
+        if (rc)
+        {
+            return rc;
+        }
         if (pp.valid && (rc = queue_step(pp, HeadingArgs<T>{0, (T)0, (T)0})))
         {
             return rc;
@@ -1052,7 +1093,6 @@ struct Ekf : EkfBase
     // ---------------------------------------------------------------- update
     int launch_factor(const T* dZ, const int* dIdf, int m, const T* R)
     {
-        const int     k = 2 * m;
         FactorArgs<T> a;
         a.X   = dX;
         a.n   = n;
@@ -1085,6 +1125,14 @@ struct Ekf : EkfBase
         a.pred_out = dPred;
         a.lds_S    = 1;
         a.lds_G    = 1;
+        return launch_factor_args(a, dU, stream);
+    }
+
+    // dispatch on k (a.m); du: the X-update vector u = G (G^T V)
+    int launch_factor_args(FactorArgs<T>& a, T* du, hipStream_t st)
+    {
+        const int k = 2 * a.m, m = a.m;
+        const bool own = (a.dM == nullptr); // the handle's own workspace: record what the gain kernel will find
         // Which kernel factorises S (all of them produce G^T, t, u; the tuned ones also M for the gain kernel's
         // pose-stripe downdate):
         //   k <= 16            ekf_factor_small_kernel: one wave, a row per lane, v_readlane broadcasts
@@ -1093,30 +1141,30 @@ struct Ekf : EkfBase
         //   beyond             ekf_factor_kernel: the general LDS / global-scratch form
         if (k <= 4)
         {
-            a.dM    = dM;
-            m_valid = true;
-            hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, stream, a, dU);
+            a.dM    = own ? dM : a.dM;
+            m_valid = own ? true : m_valid;
+            hipLaunchKernelGGL((ekf_factor_small_kernel<T, 4>), dim3(1), dim3(256), 0, st, a, du);
         }
         else if (k <= 16)
         {
-            a.dM    = dM;
-            m_valid = true;
-            hipLaunchKernelGGL((ekf_factor_small_kernel<T, 16>), dim3(1), dim3(256), 0, stream, a, dU);
+            a.dM    = own ? dM : a.dM;
+            m_valid = own ? true : m_valid;
+            hipLaunchKernelGGL((ekf_factor_small_kernel<T, 16>), dim3(1), dim3(256), 0, st, a, du);
         }
         else if (k <= 64)
         {
-            a.dM      = dM;
-            m_valid   = true;
-            g_from_gt = true;
+            a.dM      = own ? dM : a.dM;
+            m_valid   = own ? true : m_valid;
+            g_from_gt = own ? true : g_from_gt;
             if constexpr (std::is_same<T, float>::value)
             {
                 if (k <= 32)
                 {
-                    hipLaunchKernelGGL((ekf_factor_mfma_f32<32>), dim3(1), dim3(256), 0, stream, a, dU);
+                    hipLaunchKernelGGL((ekf_factor_mfma_f32<32>), dim3(1), dim3(256), 0, st, a, du);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((ekf_factor_mfma_f32<64>), dim3(1), dim3(256), 0, stream, a, dU);
+                    hipLaunchKernelGGL((ekf_factor_mfma_f32<64>), dim3(1), dim3(256), 0, st, a, du);
                 }
             }
             else
@@ -1127,11 +1175,11 @@ struct Ekf : EkfBase
                 };
                 if (k <= 32)
                 {
-                    hipLaunchKernelGGL((ekf_factor_mfma_f64<32>), dim3(1), dim3(256), lds64(32), stream, a, dU);
+                    hipLaunchKernelGGL((ekf_factor_mfma_f64<32>), dim3(1), dim3(256), lds64(32), st, a, du);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((ekf_factor_mfma_f64<64>), dim3(1), dim3(256), lds64(64), stream, a, dU);
+                    hipLaunchKernelGGL((ekf_factor_mfma_f64<64>), dim3(1), dim3(256), lds64(64), st, a, du);
                 }
             }
         }
@@ -1142,10 +1190,10 @@ struct Ekf : EkfBase
                 constexpr int K   = 128;
                 const size_t  lds = (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(float) +
                                    (size_t)(K / 2 + 4) * sizeof(int) + 16;
-                a.dM      = dM;
-                m_valid   = true;
-                g_from_gt = true;
-                hipLaunchKernelGGL((ekf_factor_mfma_big_f32<128>), dim3(1), dim3(256), lds, stream, a, dU);
+                a.dM      = own ? dM : a.dM;
+                m_valid   = own ? true : m_valid;
+                g_from_gt = own ? true : g_from_gt;
+                hipLaunchKernelGGL((ekf_factor_mfma_big_f32<128>), dim3(1), dim3(256), lds, st, a, du);
             }
         }
         else
@@ -1155,7 +1203,7 @@ struct Ekf : EkfBase
             a.lds_S      = (mat + small <= kLdsBudget) ? 1 : 0;
             a.lds_G      = (a.lds_S && 2 * mat + small <= kLdsBudget) ? 1 : 0;
             size_t lds   = small + (a.lds_S ? mat : 0) + (a.lds_G ? mat : 0);
-            hipLaunchKernelGGL(ekf_factor_kernel<T>, dim3(1), dim3(kFactorThreads), lds, stream, a);
+            hipLaunchKernelGGL(ekf_factor_kernel<T>, dim3(1), dim3(kFactorThreads), lds, st, a);
         }
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
@@ -1163,11 +1211,18 @@ struct Ekf : EkfBase
 
     // W1 of this update goes to `slot` (n_pad x k8 columns of the pending store); then the pose stripe takes its share
     // of the downdate at once and the panel's pose rows are zeroed (ekf_pose_downdate_kernel)
-    int launch_gain(int k, T* slot)
+    int launch_gain(int k, T* slot, const T* Gt = nullptr, const T* U = nullptr, const T* M = nullptr)
     {
+        // (Gt / U / M: the factor outputs to apply -- the handle's own workspace unless a look-ahead window passes a slot's)
         const int n_pad    = round_up(n, kTile);
         pose_fused_in_gain = false;
-        if (!launch_gain_fast(k, n_pad, slot))
+        if (Gt == nullptr)
+        {
+            Gt = dGt;
+            U  = dU;
+            M  = m_valid ? dM : nullptr;
+        }
+        if (!launch_gain_fast(k, n_pad, slot, Gt, U, M))
         {
             // the general vector-unit form (f32 beyond k = 128, f64 beyond k = 64): no X vector u, no fused pose downdate
             hipLaunchKernelGGL(ekf_gain_kernel<T>, dim3(n_pad / 64), dim3(256), 0, stream, dPHT, ldp, n, n_pad, k, dGt, dt_,
@@ -1188,7 +1243,7 @@ struct Ekf : EkfBase
     int  launch_downdate(const T* W, int k, hipStream_t st);
     bool launch_corr_fast(int k, const T* Wp, int kc);          // PHT -= Wp*Y^T on MFMA (f32)
     int  ensure_tile_list(int tiles);
-    bool launch_gain_fast(int k, int n_pad, T* slot); // MFMA gain (f32, k <= 128 where du is available)
+    bool launch_gain_fast(int k, int n_pad, T* slot, const T* Gt, const T* U, const T* M); // MFMA gain
 
     // one batch of m observations with device-resident Z / idf (slam.h:235-266 via EKF.cpp:93-129).
     // keep_pending: never start this update's (or any pending) P-GEMM inside the call (sequential mode).
@@ -1240,6 +1295,7 @@ struct Ekf : EkfBase
             return rc;
         }
         last_k = k;
+        dbgS = dbgGt = dbgV = nullptr; // (debug_last_update reads the handle's own workspace again)
         if ((rc = prof_begin(CSLAM_STAGE_GATHER)))
         {
             return rc;
@@ -1404,6 +1460,396 @@ struct Ekf : EkfBase
         return CSLAM_OK;
     }
 
+
+    // ---------------------------------------------------------------- look-ahead windows (ekf_lookahead.hpp)
+    // Asynchronous batch updates (16 < k <= 64) are collected two at a time.  For a window (a, b):
+    //   stream   : rows / blocks kernels (small blocks of the current P for the factor chain)
+    //   stream F : prefactor(a), factor(a), prefactor(b), factor(b) -- 1-workgroup kernels, ~60 us in all
+    //   stream   : P-GEMM of the PREVIOUS window (k = 128), under which stream F runs;
+    //              then gather(a), gain(a), gather(b) (corrected for W1_a in the kernel), gain(b) with the factors known.
+    // The state the rest of the engine sees afterwards is the deferred engine's after two updates (k_a + k_b pending
+    // columns in the store), so every other call simply drains the queue first (la_drain) and carries on.
+    struct LaUpd
+    {
+        const T*       dZ;
+        const int*     dIdf;
+        int            m;
+        T              R[4];
+        PredictArgs<T> pp;
+    };
+    struct FactorOut
+    {
+        T *  S = nullptr, *G = nullptr, *Gt = nullptr, *V = nullptr, *t = nullptr, *U = nullptr, *M = nullptr;
+        T *  sub = nullptr, *xloc = nullptr;
+        int* idloc = nullptr;
+    };
+    LaUpd       la_q[2];
+    int         la_n = 0;
+    FactorOut   fo[2];
+    hipStream_t stream_f = nullptr;
+    hipEvent_t  ev_fb = nullptr; // the chain kernel of the last window has finished
+    T *         la_XL = nullptr, *la_PvL = nullptr, *la_WR = nullptr, *la_PH = nullptr, *la_PvLb = nullptr, *la_Dbb = nullptr;
+    T*          la_Y = nullptr;         // H_b * W1_a of the last window (for a fused wide kernel)
+    LaModel<T>* la_model = nullptr;     // [2]: predict + observation model of update a / b
+    int         la_kpad  = 0;
+    long long   la_windows = 0; // windows launched (diagnostics)
+    int         la_cus = 0;        // compute units the persistent P-GEMM leaves to the chain kernel (0 until stream F exists)
+    unsigned*   la_done   = nullptr; // device counter: workgroups of the blocks kernels that have finished
+    unsigned    la_target = 0;       // its value once every blocks kernel launched so far has finished
+
+    // dynamic LDS of the chain kernel: the carry step's arrays; in f64 the factor body's arrays live in the same space
+    static size_t la_chain_lds()
+    {
+        size_t need = la_carry_lds<T>();
+        if (sizeof(T) == 8)
+        {
+            constexpr int K = 64;
+            need = std::max(need, (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(double) +
+                                      (size_t)(K / 2 + 4) * sizeof(int) + 16);
+        }
+        return std::max(need, (size_t)100 * 1024 - (sizeof(T) == 4 ? 54 * 1024 : 0)); // (enough to keep the unit to itself)
+    }
+    long long*  la_stamps  = nullptr; // CSLAM_LA_STAMPS=1: phase stamps of factor(a) underneath the P-GEMM (diagnostics)
+    // what debug_last_update reads (the handle's workspace, or the factor slot of a window's last update)
+    const T *dbgS = nullptr, *dbgGt = nullptr, *dbgV = nullptr;
+
+    void la_free()
+    {
+        for (FactorOut& f : fo)
+        {
+            (void)hipFree(f.S);
+            (void)hipFree(f.G);
+            (void)hipFree(f.Gt);
+            (void)hipFree(f.V);
+            (void)hipFree(f.t);
+            (void)hipFree(f.U);
+            (void)hipFree(f.M);
+            (void)hipFree(f.sub);
+            (void)hipFree(f.xloc);
+            (void)hipFree(f.idloc);
+            f = FactorOut();
+        }
+        (void)hipFree(la_XL);
+        (void)hipFree(la_PvL);
+        (void)hipFree(la_WR);
+        (void)hipFree(la_PH);
+        (void)hipFree(la_PvLb);
+        (void)hipFree(la_Dbb);
+        (void)hipFree(la_Y);
+        (void)hipFree(la_model);
+        (void)hipFree(la_stamps);
+        (void)hipFree(la_done);
+        la_stamps = nullptr;
+        la_done   = nullptr;
+        la_XL = la_PvL = la_WR = la_PH = la_PvLb = la_Dbb = la_Y = nullptr;
+        la_model = nullptr;
+        la_kpad  = 0;
+    }
+
+    int la_ensure(int kp_cols)
+    {
+        constexpr int KM = 2 * kLaMaxObs;
+        if (stream_f == nullptr)
+        {
+            // The chain kernel owns its compute unit by the LDS it asks for (see ekf_la_chain_kernel); the persistent
+            // P-GEMM's grid is reduced by that unit's two workgroups (la_cus).
+            int lo = 0, hi = 0;
+            CSLAM_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream_f, hipStreamNonBlocking, hi));
+            la_cus = 1;
+            CSLAM_HIP_TRY(hipEventCreateWithFlags(&ev_fb, hipEventDisableTiming));
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_la_chain_kernel<T, 32>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds()));
+            CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_la_chain_kernel<T, 64>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds()));
+            CSLAM_HIP_TRY(hipMalloc(&la_done, sizeof(unsigned)));
+            CSLAM_HIP_TRY(hipMemset(la_done, 0, sizeof(unsigned)));
+            la_target = 0;
+            for (FactorOut& f : fo)
+            {
+                CSLAM_HIP_TRY(hipMalloc(&f.S, (size_t)KM * (KM + 1) * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.G, (size_t)KM * (KM + 1) * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.Gt, (size_t)KM * (KM + 1) * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.V, (size_t)KM * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.t, (size_t)KM * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.U, (size_t)KM * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.M, (size_t)3 * KM * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.sub, (size_t)(3 + KM) * KM * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.xloc, (size_t)(3 + KM) * sizeof(T)));
+                CSLAM_HIP_TRY(hipMalloc(&f.idloc, (size_t)kLaMaxObs * sizeof(int)));
+            }
+            CSLAM_HIP_TRY(hipMalloc(&la_XL, (size_t)2 * KM * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&la_PvL, (size_t)2 * KM * 3 * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&la_PH, (size_t)KM * KM * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&la_PvLb, (size_t)KM * 3 * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&la_Dbb, (size_t)KM * KM * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&la_Y, (size_t)KM * KM * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&la_model, 2 * sizeof(LaModel<T>)));
+            if (getenv("CSLAM_LA_STAMPS"))
+            {
+                CSLAM_HIP_TRY(hipMalloc(&la_stamps, 16 * sizeof(long long)));
+                CSLAM_HIP_TRY(hipMemset(la_stamps, 0, 16 * sizeof(long long)));
+            }
+        }
+        if (kp_cols > la_kpad)
+        {
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream_f));
+            (void)hipFree(la_WR);
+            la_WR   = nullptr;
+            la_kpad = 0;
+            const int kpad = round_up(std::max(kp_cols, 128), 64);
+            CSLAM_HIP_TRY(hipMalloc(&la_WR, (size_t)2 * KM * kpad * sizeof(T)));
+            la_kpad = kpad;
+        }
+        return CSLAM_OK;
+    }
+
+    // may this batch join a look-ahead window?  (everything the window's fixed schedule does not cover stays classic)
+    bool la_eligible(int m) const
+    {
+        const int k = 2 * m;
+        // lookahead: 1 on, 0 off, -1 (default) where it pays: f32 and a P-GEMM long enough to hide the factor chain
+        // (~70 us) underneath it -- about N >= 3500 landmarks; a short P-GEMM leaves the chain on the critical path
+        // (measured: f64 N = 1000 12.9 k steps/s with windows against 15.8 k without)
+        const bool on = lookahead > 0 || (lookahead < 0 && sizeof(T) == 4 && n >= 7000);
+        return on && !sync_mode && !pipeline && profiling != 1 && k > 16 && k <= 2 * kLaMaxObs && gather_corr_wide &&
+               fuse_predict && (sizeof(T) == 4 || fuse_f64) && defer_max >= k + (la_n ? 2 * la_q[0].m : k) &&
+               wcap >= k + (la_n ? 2 * la_q[0].m : k) && seq.count == 0 && hd_cols[0] == 0 && hd_cols[1] == 0 && n > 3 &&
+               kp_call_limit == 0;
+    }
+
+    int la_enqueue(const T* dZ, const int* dIdf, int m, const T* R)
+    {
+        LaUpd u;
+        u.dZ   = dZ;
+        u.dIdf = dIdf;
+        u.m    = m;
+        for (int i = 0; i < 4; i++)
+        {
+            u.R[i] = R[i];
+        }
+        u.pp     = pp; // the held predict belongs to this update
+        pp.valid = 0;
+        la_q[la_n++] = u;
+        return la_n == 2 ? la_launch_window() : CSLAM_OK;
+    }
+
+    // the factor kernel's arguments for one update of a window: compact inputs (a local state vector of 3 + 2m entries with
+    // local feature ids 1..m and the block sub), outputs into the factor slot f
+    FactorArgs<T> la_factor_args(const LaUpd& u, FactorOut& f)
+    {
+        FactorArgs<T> a;
+        a.X   = f.xloc;
+        a.n   = 3 + 2 * u.m;
+        a.Z   = u.dZ;
+        a.idf = fo[0].idloc; // 1, 2, ... (written once per window by the blocks kernel)
+        a.m   = u.m;
+        for (int i = 0; i < 4; i++)
+        {
+            a.R[i] = u.R[i];
+        }
+        a.PHT      = dPHT; // (not read: the compact block is supplied)
+        a.ldw      = ldp;
+        a.dS       = f.S;
+        a.dG       = f.G;
+        a.dGt      = f.Gt;
+        a.dV       = f.V;
+        a.dt       = f.t;
+        a.flags    = dFlags;
+        a.scratchS = dScrS;
+        a.scratchG = dScrG;
+        a.textbook = (quirks & CSLAM_Q_LOWER_CHOL_GAIN) ? 0 : 1;
+        a.stamps   = (la_stamps && &f == &fo[0]) ? la_stamps : nullptr;
+        a.sub      = f.sub;
+        a.dM       = f.M;
+        a.pp       = PredictArgs<T>{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0}; // (applied by blocks / carry)
+        a.P3       = dPv;
+        a.ldp3     = ldp;
+        a.pred_out = nullptr;
+        a.lds_S    = 1;
+        a.lds_G    = 1;
+        return a;
+    }
+
+    // gather + gain of one update of the window on the main stream, with the factor outputs of slot f
+    int la_wide(const LaUpd& u, const FactorOut& f, hipEvent_t ev_factor)
+    {
+        const int k = 2 * u.m;
+        pp          = u.pp;
+        fuse_now    = pp.valid != 0;
+        if (fuse_now && dPred == nullptr)
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dPred, 16 * sizeof(T)));
+        }
+        last_k = k;
+        PredictArgs<T> pnone{0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, 0};
+        PredictArgs<T> pa   = fuse_now ? pp : pnone;
+        T*             pred = fuse_now ? dPred : (T*)nullptr;
+        const T*       Wg   = kp > 0 ? (const T*)wbase(wcur) : (const T*)nullptr;
+        if (kp > kGatherCorr)
+        {
+            const dim3 wgrid((n + 255) / 256, (u.m + kGatherObsWide - 1) / kGatherObsWide);
+            hipLaunchKernelGGL((ekf_gather_kernel<T, kGatherCorrMax, kGatherObsWide>), wgrid, dim3(256), 0, stream, dX, dP, dPv,
+                               ldp, n, u.dZ, u.dIdf, u.m, dPHT, ldp, lower, (T*)nullptr, pa, pred, Wg, ldp, kp,
+                               (const int*)nullptr, dFlags, (T*)nullptr);
+        }
+        else
+        {
+            const dim3 ggrid((n + 255) / 256, (u.m + kGatherObs - 1) / kGatherObs);
+            hipLaunchKernelGGL(ekf_gather_kernel<T>, ggrid, dim3(256), 0, stream, dX, dP, dPv, ldp, n, u.dZ, u.dIdf, u.m, dPHT,
+                               ldp, lower, (T*)nullptr, pa, pred, Wg, ldp, kp, (const int*)nullptr, dFlags, (T*)nullptr);
+        }
+        CSLAM_HIP_TRY(hipGetLastError());
+        if (ev_factor != nullptr)
+        {
+            CSLAM_HIP_TRY(hipStreamWaitEvent(stream, ev_factor, 0));
+        }
+        T*  slot = wbase(wcur) + (size_t)kp * ldp;
+        int rc   = launch_gain(k, slot, f.Gt, f.U, f.M);
+        if (rc)
+        {
+            return rc;
+        }
+        pp.valid  = 0;
+        fuse_now  = false;
+        last_slot = slot;
+        kp += k;
+        dbgS      = f.S;
+        dbgGt     = f.Gt;
+        dbgV      = f.V;
+        g_from_gt = true;
+        sub_valid = false;
+        return CSLAM_OK;
+    }
+
+    int la_launch_window()
+    {
+        const int nu = la_n;
+        if (nu == 0)
+        {
+            return CSLAM_OK;
+        }
+        la_n = 0;
+        const LaUpd ua = la_q[0], ub = la_q[1];
+        const PredictArgs<T> held = pp; // a predict accepted AFTER the queued updates stays held
+        int rc = use_device();
+        if (rc)
+        {
+            return rc;
+        }
+        const int ka = 2 * ua.m, kb = nu == 2 ? 2 * ub.m : 0;
+        if (kp > 256 && (rc = flush())) // (the blocks kernel stages one row of at most 256 pending columns)
+        {
+            return rc;
+        }
+        if ((rc = ensure_k(2 * kLaMaxObs)) || (rc = ensure_w(ka + kb)) || (rc = la_ensure(kp)))
+        {
+            return rc;
+        }
+        // 1. the factor chain of the window on stream F, ONE launch, submitted first: it takes a compute unit for itself
+        //    and waits there (on a counter) for the blocks kernel below
+        const unsigned n_blocks = (unsigned)(3 + ka + 2 * kb);
+        {
+            LaChainArgs<T> ch;
+            ch.fa   = la_factor_args(ua, fo[0]);
+            ch.fb   = la_factor_args(nu == 2 ? ub : ua, fo[1]);
+            ch.du_a = fo[0].U;
+            ch.du_b = fo[1].U;
+            ch.nu   = nu;
+            ch.done = la_done;
+            ch.target  = la_target + n_blocks;
+            ch.timeout = 20000000ull; // 0.2 s of s_memrealtime ticks
+            LaCarryArgs<T>& ca = ch.ca;
+            ca.n       = n;
+            ca.m_a     = ua.m;
+            ca.m_b     = nu == 2 ? ub.m : 0;
+            ca.idf_b   = nu == 2 ? ub.dIdf : ua.dIdf;
+            ca.pp_b    = nu == 2 ? ub.pp : ua.pp;
+            ca.PH      = la_PH;
+            ca.Dbb     = la_Dbb;
+            ca.PvLb    = la_PvLb;
+            ca.XLb     = la_XL + ka;
+            ca.model_a = la_model;
+            ca.Gt_a    = fo[0].Gt;
+            ca.u_a     = fo[0].U;
+            ca.M_a     = fo[0].M;
+            ca.sub_a   = fo[0].sub;
+            ca.sub_b   = fo[1].sub;
+            ca.xloc_b  = fo[1].xloc;
+            ca.model_b = la_model + 1;
+            ca.Y_b     = la_Y;
+            if (std::max(ka, kb) <= 32)
+            {
+                hipLaunchKernelGGL((ekf_la_chain_kernel<T, 32>), dim3(1), dim3(256), la_chain_lds(), stream_f, ch);
+            }
+            else
+            {
+                hipLaunchKernelGGL((ekf_la_chain_kernel<T, 64>), dim3(1), dim3(256), la_chain_lds(), stream_f, ch);
+            }
+            CSLAM_HIP_TRY(hipGetLastError());
+            CSLAM_HIP_TRY(hipEventRecord(ev_fb, stream_f));
+        }
+        // 2. what the chain needs of the current covariance P = Ps - Wp Wp^T (before Ps changes): rows of the pending
+        //    panels, then one workgroup per row of the small blocks; update a's compact block sub_a comes out of it ready
+        //    for the factor step.  (From here to the blocks launch nothing may fail: the chain kernel is waiting.)
+        const T* Wp = wbase(wcur);
+        hipLaunchKernelGGL(ekf_la_rows_kernel<T>, dim3(ka + kb), dim3(128), 0, stream, dX, dPv, ldp, n, ua.dIdf, ka,
+                           nu == 2 ? ub.dIdf : ua.dIdf, kb, Wp, ldp, kp, la_kpad, la_XL, la_PvL, la_WR);
+        LaPrepArgs<T> pa;
+        pa.P       = dP;
+        pa.ldp     = ldp;
+        pa.n       = n;
+        pa.lower   = lower;
+        pa.X       = dX;
+        pa.Pv      = dPv;
+        pa.idf_a   = ua.dIdf;
+        pa.idf_b   = nu == 2 ? ub.dIdf : ua.dIdf;
+        pa.ra      = ka;
+        pa.rb      = kb;
+        pa.pp_a    = ua.pp;
+        pa.XL      = la_XL;
+        pa.PvL     = la_PvL;
+        pa.WR      = la_WR;
+        pa.kp      = kp;
+        pa.kpad    = la_kpad;
+        pa.sub_a   = fo[0].sub;
+        pa.PH      = la_PH;
+        pa.Dbb     = la_Dbb;
+        pa.PvLb    = la_PvLb;
+        pa.model_a = la_model;
+        pa.xloc_a  = fo[0].xloc;
+        pa.idloc   = fo[0].idloc;
+        pa.done    = la_done;
+        hipLaunchKernelGGL(ekf_la_blocks_kernel<T>, dim3(n_blocks), dim3(64), 0, stream, pa);
+        CSLAM_HIP_TRY(hipGetLastError());
+        la_target += n_blocks;
+        // 3. the P-GEMM of everything pending (the previous window's panels): stream F works underneath it
+        if ((rc = flush()))
+        {
+            return rc;
+        }
+        // 4. the wide kernels of both updates, factors known
+        if ((rc = la_wide(ua, fo[0], ev_fb)) || (nu == 2 && (rc = la_wide(ub, fo[1], nullptr))))
+        {
+            return rc;
+        }
+        pp = held;
+        la_windows++;
+        if (la_stamps && la_windows == 300)
+        {
+            long long h[16];
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            CSLAM_HIP_TRY(hipMemcpy(h, la_stamps, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[cslam la stamps, cycles] load+observe:%lld sums:%lld symmetrise:%lld cholesky:%lld (first half %lld) inverse:%lld outputs:%lld total:%lld\n",
+                    h[6] - h[0], h[7] - h[6], h[1] - h[7], h[2] - h[1], h[5] ? h[5] - h[1] : 0, h[3] - h[2], h[4] - h[3], h[4] - h[0]);
+        }
+        return CSLAM_OK;
+    }
+
+    // every call that needs the state as of the last update() goes through here first
+    int la_drain() override { return la_n ? la_launch_window() : CSLAM_OK; }
+
     int update(const void* Zv, int m, const void* Rv, const int* idf, int batch, bool on_device) override
     {
         if (m < 0 || !Rv || (m > 0 && (!Zv || !idf)))
@@ -1436,6 +1882,14 @@ struct Ekf : EkfBase
             {
                 return rc;
             }
+        }
+        if (batch && la_eligible(m))
+        {
+            return la_enqueue(dZ, dIdf, m, R);
+        }
+        if ((rc = la_drain())) // (the held predict of THIS call survives the drain: la_launch_window keeps it)
+        {
+            return rc;
         }
         if (batch)
         {
@@ -1535,7 +1989,7 @@ struct Ekf : EkfBase
             return fail(CSLAM_ERR_BAD_ARG, "factor_status: null");
         }
         int rc = use_device();
-        if (rc)
+        if (rc || (rc = la_drain()))
         {
             return rc;
         }
@@ -1549,6 +2003,10 @@ struct Ekf : EkfBase
         if (hFlags[0] & kFlagBadIdf)
         {
             f |= CSLAM_FACTOR_BAD_IDF;
+        }
+        if (hFlags[0] & kFlagLaTimeout)
+        {
+            f |= CSLAM_FACTOR_INTERNAL;
         }
         if ((hFlags[0] & kFlagLltFailed) && !(sticky_host & CSLAM_FACTOR_FALLBACK))
         {
@@ -1617,7 +2075,7 @@ struct Ekf : EkfBase
         }
         if (S)
         {
-            CSLAM_HIP_TRY(hipMemcpyAsync(S, dS, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipMemcpyAsync(S, dbgS ? dbgS : dS, (size_t)k * k * sizeof(T), hipMemcpyDeviceToHost, stream));
         }
         if (G && !g_from_gt)
         {
@@ -1626,7 +2084,7 @@ struct Ekf : EkfBase
         if (G && g_from_gt) // the tuned factor kernels publish only G^T (what the gain kernel reads)
         {
             std::vector<T> Gt((size_t)k * k);
-            CSLAM_HIP_TRY(hipMemcpyAsync(Gt.data(), dGt, Gt.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipMemcpyAsync(Gt.data(), dbgGt ? dbgGt : dGt, Gt.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
             CSLAM_HIP_TRY(hipStreamSynchronize(stream));
             T* out = static_cast<T*>(G);
             for (int c = 0; c < k; c++)
@@ -1639,7 +2097,7 @@ struct Ekf : EkfBase
         }
         if (V)
         {
-            CSLAM_HIP_TRY(hipMemcpyAsync(V, dV, (size_t)k * sizeof(T), hipMemcpyDeviceToHost, stream));
+            CSLAM_HIP_TRY(hipMemcpyAsync(V, dbgV ? dbgV : dV, (size_t)k * sizeof(T), hipMemcpyDeviceToHost, stream));
         }
         CSLAM_HIP_TRY(hipStreamSynchronize(stream));
         return CSLAM_OK;
@@ -1692,7 +2150,9 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
     // Persistent grid: two workgroups per CU, minus `pgemm_spare` in two-stream mode -- a few CUs keep one workgroup
     // (64 of 160 KB LDS) so that the one-workgroup factor kernel of the NEXT update (53 KB LDS, stream A) finds room
     // while this P-GEMM fills the chip.
-    int G = std::min(n_sym_tiles, std::max(1, 2 * num_cus - (pipeline ? pgemm_spare : 0)));
+    // (two-stream mode: a few CUs keep one workgroup; look-ahead windows: the main stream's queue mask excludes the
+    // compute units of the factor chain's stream, see la_ensure)
+    int G = std::min(n_sym_tiles, std::max(1, 2 * (num_cus - la_cus) - (pipeline ? pgemm_spare : 0)));
     if (pgemm_wgs > 0)
     {
         G = std::min(G, pgemm_wgs);
@@ -1813,16 +2273,16 @@ int Ekf<float>::launch_downdate(const float* W, int k, hipStream_t stream)
 }
 
 template <>
-bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot)
+bool Ekf<float>::launch_gain_fast(int k, int n_pad, float* slot, const float* Gt, const float* U, const float* M)
 {
     if (k > 128)
     {
         return false; // u is produced by the tuned factor kernels only
     }
     hipLaunchKernelGGL((ekf_panel_mfma_f32<false, true>), dim3(n_pad / 32, (k + 31) / 32), dim3(64), 0, stream, dPHT, ldp, n,
-                       k, k, dGt, k, dU, slot, ldp, dX, fuse_now ? (const float*)dPred : (const float*)nullptr, pp.w, dPv, ldp,
-                       m_valid ? (const float*)dM : (const float*)nullptr, dWv);
-    pose_fused_in_gain = m_valid;
+                       k, k, Gt, k, U, slot, ldp, dX, fuse_now ? (const float*)dPred : (const float*)nullptr, pp.w, dPv, ldp,
+                       M, dWv);
+    pose_fused_in_gain = (M != nullptr);
     return true;
 }
 
@@ -1845,16 +2305,16 @@ bool Ekf<double>::launch_corr_fast(int k, const double* Wp, int kc)
 }
 
 template <>
-bool Ekf<double>::launch_gain_fast(int k, int n_pad, double* slot)
+bool Ekf<double>::launch_gain_fast(int k, int n_pad, double* slot, const double* Gt, const double* U, const double* M)
 {
     if (k > 64) // u (and M) come from the tuned factor kernels
     {
         return false;
     }
     hipLaunchKernelGGL((ekf_panel_mfma_f64<false, true>), dim3(n_pad / 16, (k + 15) / 16), dim3(64), 0, stream, dPHT, ldp, n, k,
-                       k, dGt, k, dU, slot, ldp, dX, dPv, ldp, m_valid ? (const double*)dM : (const double*)nullptr, dWv,
-                       fuse_now ? (const double*)dPred : (const double*)nullptr, pp.w);
-    pose_fused_in_gain = m_valid;
+                       k, Gt, k, U, slot, ldp, dX, dPv, ldp, M, dWv, fuse_now ? (const double*)dPred : (const double*)nullptr,
+                       pp.w);
+    pose_fused_in_gain = (M != nullptr);
     return true;
 }
 
@@ -2014,6 +2474,10 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
     {
         b->limbs_kmin_req = atoi(lk);
     }
+    if (const char* lv = getenv("CSLAM_LOOKAHEAD"))
+    {
+        b->lookahead = atoi(lv) > 0 ? 1 : (atoi(lv) < 0 ? -1 : 0);
+    }
     if (const char* gw = getenv("CSLAM_GATHER_WIDE"))
     {
         b->gather_corr_wide = atoi(gw) ? 1 : 0;
@@ -2052,6 +2516,10 @@ int cslam_ekf_destroy(cslam_ekf_t h)
 int cslam_ekf_set_sync_mode(cslam_ekf_t h, int sync_mode)
 {
     CSLAM_NEED(h);
+    if (int rc = B(h)->la_drain()) // (queued look-ahead updates belong to the asynchronous mode they were accepted in)
+    {
+        return rc;
+    }
     B(h)->sync_mode = sync_mode ? 1 : 0;
     return CSLAM_OK;
 }

@@ -388,8 +388,10 @@ __global__ void __launch_bounds__(256) ekf_factor_small_kernel(FactorArgs<T> a, 
 //   inverse step q:   X[q][:] = R[q][:] * rs_q -> G in LDS,  R -= L[:, q] X[q][:]  (R starts as I; 2 MFMAs)
 // 64 + 64 short dependent steps (~120 cycles each) instead of 2 x 2016 broadcast pairs.
 // ------------------------------------------------------------------------------------------------
+// (a __device__ body: the kernel below runs it as one workgroup; the look-ahead chain kernel, ekf_lookahead.hpp, runs it
+// twice in one launch with the carry step in between)
 template <int K>
-__global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, float* __restrict__ du)
+__device__ __forceinline__ void ekf_factor_mfma_f32_body(const FactorArgs<float>& a, float* __restrict__ du)
 {
     static_assert(K == 32 || K == 64, "one or two 32-wide tiles per dimension");
     typedef float  T;
@@ -835,6 +837,12 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, 
     }
 }
 
+template <int K>
+__global__ void __launch_bounds__(256) ekf_factor_mfma_f32(FactorArgs<float> a, float* __restrict__ du)
+{
+    ekf_factor_mfma_f32_body<K>(a, du);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2+K3 (f64) for 16 < k <= 64 on v_mfma_f64_16x16x4_f64: the f64 counterpart of ekf_factor_mfma_f32.
 //
@@ -876,8 +884,10 @@ __device__ inline double rsqrt_f64(double d)
     return y;
 }
 
+// (a __device__ body: the kernel below runs it as one workgroup; the look-ahead chain kernel, ekf_lookahead.hpp, runs it
+// twice in one launch with the carry step in between)
 template <int K>
-__global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a, double* __restrict__ du)
+__device__ __forceinline__ void ekf_factor_mfma_f64_body(const FactorArgs<double>& a, double* __restrict__ du)
 {
     static_assert(K == 32 || K == 64, "two or four 16-wide tiles per dimension");
     typedef double T;
@@ -1325,6 +1335,12 @@ __global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a,
             atomicOr(&a.flags[0], code);
         }
     }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) ekf_factor_mfma_f64(FactorArgs<double> a, double* __restrict__ du)
+{
+    ekf_factor_mfma_f64_body<K>(a, du);
 }
 
 // ------------------------------------------------------------------------------------------------

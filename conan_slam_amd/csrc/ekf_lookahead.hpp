@@ -1,0 +1,732 @@
+// ekf_lookahead.hpp -- the small-matrix side of the LOOK-AHEAD update engine (cslam_ekf.hip, "look-ahead windows").
+//
+// The batch update of slam.h:235-266 is a strict chain per update -- gather PHT = P H^T (n x k), factor S (k x k, one
+// workgroup, ~22 us), gain W1 = PHT G (n x k) -- and the covariance downdate P -= W1 W1^T (the P-GEMM) sweeps all of P.
+// But the factorisation only ever looks at the (3 + 2m) x (3 + 2m) principal block of P over the pose and the m observed
+// landmarks, and at 3 + 2m entries of X:
+//     S = H P H^T + R,   H non-zero in the pose columns and the two columns of every observed landmark (EKF.cpp:394-395).
+// So the factor chain of the NEXT two updates can run ahead on a stream of its own, from a few small blocks of the
+// current P, while the wide kernels (gather, gain, P-GEMM) of the previous updates still occupy the chip:
+//
+//   ekf_la_rows_kernel     rows of X, of the pose stripe Pv and of the pending W1 panels at the landmark rows of the
+//                          window's two updates a and b                                       (main stream, many workgroups)
+//   ekf_la_blocks_kernel   one workgroup per row of the blocks D_aa, D_ba, D_bb of the TRUE covariance P = Ps - Wp Wp^T
+//                          between those rows (Ps block-lower in HBM, Wp the pending panels).  Every workgroup also
+//                          applies update a's held predict (EKF.cpp:406-455) to its row and evaluates a's observation
+//                          model (EKF.cpp:354-404), so the rows leave as what the factor chain needs: row of
+//                          sub_a = PHT_a[rows(a), :] (ekf_gather_kernel's compact block), row of PHT_a[rows(b), :],
+//                          row of D_bb                                                         (main stream, many workgroups)
+//   ekf_la_carry_kernel    update b on stream F, between the two factor kernels: carries the rows of b through update a
+//                          WITHOUT the wide kernels -- W1_a[rows(b)] = PHT_a[rows(b)] G_a, P[rows(b), rows(b)] -= W1 W1^T,
+//                          X[rows(b)] += PHT_a[rows(b)] u_a, the pose stripe rows -= PHT_a M_a (slam.h:257-260 restricted
+//                          to 67 rows) -- then b's predict and observation model, and forms sub_b.  One workgroup; every
+//                          global load is issued up front (under the P-GEMM a round trip costs microseconds), the two
+//                          64 x 64 x 64 products run on 4 x 4 register tiles fed by 16-byte LDS reads.
+// The factor kernels themselves (ekf_factor_mfma_f32 / _f64) run unchanged on these compact inputs (a local state vector
+// of 3 + 2m entries with local feature ids 1..m).  The wide kernels then apply both updates to all n rows afterwards
+// with the factors already known.  Same algebra as the reference's sequence of two choleskyUpdate calls, re-associated;
+// results agree to rounding (tests/test_timed_path_gpu.py runs this path against the oracle).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ekf_kernels.hpp"
+#include "ekf_kernels_fast.hpp"
+
+namespace cslam
+{
+
+constexpr int kLaMaxObs = 32; // observations per update on this path (k <= 64)
+
+// 0-based state row of slot s (two per observation) of an update's landmark rows
+__device__ inline int la_row(const int* __restrict__ idf, int s, int n)
+{
+    return 3 + 2 * clamp_idf(idf[s >> 1], n) - 2 + (s & 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows: slot s < ra = 2 m_a belongs to update a, ra <= s < ra + rb to update b.
+//   XL[s] = X[row], PvL[s*3 + c] = Pv[c*ldp + row], WR[s*kpad + q] = Wp[q*ldw + row] (q < kp)
+// grid = ra + rb workgroups of 128 threads.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(128) ekf_la_rows_kernel(const T* __restrict__ X, const T* __restrict__ Pv, int ldp, int n,
+                                                           const int* __restrict__ idf_a, int ra,
+                                                           const int* __restrict__ idf_b, int rb,
+                                                           const T* __restrict__ Wp, int ldw, int kp, int kpad,
+                                                           T* __restrict__ XL, T* __restrict__ PvL, T* __restrict__ WR)
+{
+    const int s   = blockIdx.x;
+    const int row = (s < ra) ? la_row(idf_a, s, n) : la_row(idf_b, s - ra, n);
+    for (int q = threadIdx.x; q < kp; q += 128)
+    {
+        WR[(size_t)s * kpad + q] = Wp[(size_t)q * ldw + row];
+    }
+    if (threadIdx.x < 3)
+    {
+        PvL[s * 3 + threadIdx.x] = Pv[(size_t)threadIdx.x * ldp + row];
+    }
+    if (threadIdx.x == 3)
+    {
+        XL[s] = X[row];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// What an update's predict + observation model leave behind.  The head {g02, g12, pose, pvv} has the layout the
+// gain kernels read as `pred` (ekf_panel_mfma_f32).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct LaModel
+{
+    T g02, g12; // Gv entries of the update's predict (EKF.cpp:419-428; 0 when none was held)
+    T pose[3];  // pose after the predict (EKF.cpp:445-452)
+    T pvv[9];   // pose block after the predict, element (r, c) at r + 3c (EKF.cpp:430-440)
+    T coef[kLaMaxObs * 10]; // H coefficients per observation (observe_model_pose)
+};
+
+// applies a held predict to one stripe row (row index `row` >= 3): Gv * (a0, a1, a2), EKF.cpp:442-443 with the n-4 quirk
+template <typename T>
+__device__ inline void la_predict_row(const PredictArgs<T>& pp, T g02, T g12, int row, T* a)
+{
+    if (pp.valid && row - 3 < pp.w)
+    {
+        T o0, o1, o2;
+        predict_stripe_col<T>(g02, g12, a[0], a[1], a[2], &o0, &o1, &o2);
+        a[0] = o0;
+        a[1] = o1;
+        a[2] = o2;
+    }
+}
+
+// pose, Gv entries and pose block after a held predict (one thread)
+template <typename T>
+__device__ inline void la_predict_pose(const PredictArgs<T>& pp, const T* pose_in, const T* pvv_in, T* pose, T* g, T* pvv)
+{
+    pose[0] = pose_in[0], pose[1] = pose_in[1], pose[2] = pose_in[2];
+    g[0] = g[1] = (T)0;
+    for (int e = 0; e < 9; e++)
+    {
+        pvv[e] = pvv_in[e];
+    }
+    if (pp.valid)
+    {
+        predicted_pose<T>(pp, pose_in, &pose[0], &pose[1], &pose[2]);
+        predict_gv<T>(pp, pose_in[2], &g[0], &g[1]);
+        predict_pvv<T>(pp, pose_in[2], pvv_in, pvv);
+    }
+}
+
+// the five-term sums of ekf_gather_kernel for one (row, observation): columns 0, 1, 2, fx, fx+1 ascending
+template <typename T>
+__device__ inline void la_pht_pair(const T* c, T p0, T p1, T p2, T pa, T pb, T* v0, T* v1)
+{
+    T s0 = p0 * c[0];
+    s0 += p1 * c[1];
+    s0 += p2 * c[2];
+    s0 += pa * c[3];
+    s0 += pb * c[4];
+    T s1 = p0 * c[5];
+    s1 += p1 * c[6];
+    s1 += p2 * c[7];
+    s1 += pa * c[8];
+    s1 += pb * c[9];
+    *v0 = s0;
+    *v1 = s1;
+}
+
+template <typename T>
+struct LaPrepArgs
+{
+    const T* P;
+    int      ldp, n, lower;
+    const T* X;  // base state (pose X[0..2])
+    const T* Pv; // base pose stripe (its 3 x 3 head is the pose block)
+    const int* idf_a;
+    const int* idf_b;
+    int ra, rb; // 2 m_a, 2 m_b (rb = 0: a window of one update)
+    PredictArgs<T> pp_a;
+    const T *XL, *PvL, *WR; // ekf_la_rows_kernel
+    int kp, kpad;
+    // outputs
+    T* sub_a;  // (3 + ra) x ra: sub[slot*ra + col]
+    T* PH;     // rb x ra: PHT_a[rows_lm(b), :]
+    T* Dbb;    // rb x rb
+    T* PvLb;   // rb x 3: stripe rows of b after a's predict
+    LaModel<T>* model_a;
+    T*   xloc_a; // 3 + ra
+    int* idloc;  // 1 .. kLaMaxObs
+    unsigned* done; // counts finished workgroups (the chain kernel on stream F waits for this launch's share)
+};
+
+// ------------------------------------------------------------------------------------------------
+// grid = 3 + ra + 2 rb workgroups of 64 threads:
+//   b < 3              pose row b of sub_a (workgroup 0 also publishes model_a, xloc_a, idloc)
+//   b < 3 + ra         landmark row of update a: row of D_aa -> row 3 + s of sub_a
+//   b < 3 + ra + rb    landmark row of update b against the columns of a: row of D_ba -> row of PHT_a[rows_lm(b)]
+//   else               landmark row of update b against its own columns: row of D_bb
+// D[s][s'] = Ps(row s, row s') - sum_q WR[s][q] WR[s'][q] (the pending panels' pose rows are zero: pose parts come from
+// the stripe).  (s, s') and (s', s) read the same element of Ps and add the same products in the same order.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) ekf_la_blocks_kernel(LaPrepArgs<T> a)
+{
+    __shared__ T wrow[256];
+    __shared__ T s_xl[3 + 2 * kLaMaxObs];
+    __shared__ T s_coef[kLaMaxObs * 10];
+    __shared__ T s_pvv[9], s_g[2], s_e3[3];
+    __shared__ T s_d[2 * kLaMaxObs];
+    __shared__ T s_e[2 * kLaMaxObs * 3];
+    const int tid = threadIdx.x;
+    const int ra = a.ra, rb = a.rb, ma = ra >> 1;
+    int       b    = blockIdx.x;
+    int       type = 0, s = b; // 0 pose row, 1 row of a, 2 row of b vs a, 3 row of b vs b
+    if (b >= 3)
+    {
+        b -= 3;
+        type = (b < ra) ? 1 : ((b < ra + rb) ? 2 : 3);
+        s    = (type == 1) ? b : ((type == 2) ? b - ra : b - ra - rb);
+    }
+    // everything the row needs from global memory is requested before the model is evaluated
+    const int* idf_r = (type <= 1) ? a.idf_a : a.idf_b;
+    const int* idf_c = (type == 3) ? a.idf_b : a.idf_a;
+    const int  nc    = (type == 3) ? rb : ra;
+    const int  wr_r  = (type <= 1) ? s : ra + s; // row of WR / XL / PvL of this workgroup's row
+    const int  wr_c0 = (type == 3) ? ra : 0;
+    int        row   = 0;
+    T          pcell = (T)0;
+    T          e3[3] = {(T)0, (T)0, (T)0};
+    if (type != 0)
+    {
+        row = la_row(idf_r, s, a.n);
+        for (int q = tid; q < a.kp; q += 64) // (kp <= 256: the host keeps longer windows on the classic path)
+        {
+            wrow[q] = a.WR[(size_t)wr_r * a.kpad + q];
+        }
+        if (tid < nc)
+        {
+            pcell = p_sym<T>(a.P, a.ldp, row, la_row(idf_c, tid, a.n), a.lower);
+        }
+        if (tid == 0)
+        {
+            e3[0] = a.PvL[wr_r * 3 + 0], e3[1] = a.PvL[wr_r * 3 + 1], e3[2] = a.PvL[wr_r * 3 + 2];
+        }
+    }
+    T ee[3] = {(T)0, (T)0, (T)0};
+    int erow = 0;
+    if (type == 0 && tid < ra)
+    {
+        ee[0] = a.PvL[tid * 3 + 0], ee[1] = a.PvL[tid * 3 + 1], ee[2] = a.PvL[tid * 3 + 2];
+        erow  = la_row(a.idf_a, tid, a.n);
+    }
+    if (tid < ra)
+    {
+        s_xl[3 + tid] = a.XL[tid];
+    }
+    if (tid == 0)
+    {
+        T pose_in[3] = {a.X[0], a.X[1], a.X[2]}, pvv_in[9], pose[3], g[2], pvv[9];
+        for (int e = 0; e < 9; e++)
+        {
+            pvv_in[e] = a.Pv[(size_t)(e / 3) * a.ldp + (e % 3)];
+        }
+        la_predict_pose<T>(a.pp_a, pose_in, pvv_in, pose, g, pvv);
+        s_xl[0] = pose[0], s_xl[1] = pose[1], s_xl[2] = pose[2];
+        s_g[0] = g[0], s_g[1] = g[1];
+        for (int e = 0; e < 9; e++)
+        {
+            s_pvv[e] = pvv[e];
+        }
+        if (type != 0)
+        {
+            la_predict_row<T>(a.pp_a, g[0], g[1], row, e3);
+            s_e3[0] = e3[0], s_e3[1] = e3[1], s_e3[2] = e3[2];
+        }
+    }
+    __syncthreads();
+    if (tid < ma)
+    {
+        T   v[2];
+        int fx;
+        observe_model_pose<T>(s_xl, 3 + ra, tid + 1, (T)0, (T)0, s_xl[0], s_xl[1], s_xl[2], &s_coef[tid * 10], v, &fx);
+    }
+    if (type == 0)
+    {
+        if (tid < ra)
+        {
+            la_predict_row<T>(a.pp_a, s_g[0], s_g[1], erow, ee);
+            s_e[tid * 3 + 0] = ee[0], s_e[tid * 3 + 1] = ee[1], s_e[tid * 3 + 2] = ee[2];
+        }
+    }
+    else if (tid < nc)
+    {
+        const T* wc  = a.WR + (size_t)(wr_c0 + tid) * a.kpad;
+        T        dot = (T)0;
+        for (int q = 0; q < a.kp; q++)
+        {
+            dot += wrow[q] * wc[q];
+        }
+        s_d[tid] = pcell - dot;
+    }
+    __syncthreads();
+    if (type == 0)
+    {
+        const int r = s; // pose row
+        if (tid < ma)
+        {
+            T v0, v1;
+            la_pht_pair<T>(&s_coef[tid * 10], s_pvv[r], s_pvv[r + 3], s_pvv[r + 6], s_e[(2 * tid) * 3 + r],
+                           s_e[(2 * tid + 1) * 3 + r], &v0, &v1);
+            a.sub_a[r * ra + 2 * tid]     = v0;
+            a.sub_a[r * ra + 2 * tid + 1] = v1;
+        }
+        if (r == 0)
+        {
+            LaModel<T>& mo = *a.model_a;
+            if (tid == 0)
+            {
+                mo.g02 = s_g[0];
+                mo.g12 = s_g[1];
+            }
+            if (tid < 3)
+            {
+                mo.pose[tid] = s_xl[tid];
+            }
+            if (tid < 9)
+            {
+                mo.pvv[tid] = s_pvv[tid];
+            }
+            for (int e = tid; e < ma * 10; e += 64)
+            {
+                mo.coef[e] = s_coef[e];
+            }
+            for (int e = tid; e < 3 + ra; e += 64)
+            {
+                a.xloc_a[e] = s_xl[e];
+            }
+            if (tid < kLaMaxObs)
+            {
+                a.idloc[tid] = tid + 1;
+            }
+        }
+    }
+    else if (type == 3)
+    {
+        if (tid < nc)
+        {
+            a.Dbb[(size_t)s * rb + tid] = s_d[tid];
+        }
+    }
+    else
+    {
+        if (tid < ma)
+        {
+            T v0, v1;
+            la_pht_pair<T>(&s_coef[tid * 10], s_e3[0], s_e3[1], s_e3[2], s_d[2 * tid], s_d[2 * tid + 1], &v0, &v1);
+            T* out           = (type == 1) ? (a.sub_a + (size_t)(3 + s) * ra) : (a.PH + (size_t)s * ra);
+            out[2 * tid]     = v0;
+            out[2 * tid + 1] = v1;
+        }
+        if (type == 2 && tid < 3)
+        {
+            a.PvLb[s * 3 + tid] = s_e3[tid];
+        }
+    }
+    // this workgroup's rows are out: release them to the chain kernel (device scope: it may run on another XCD)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0)
+    {
+        atomicAdd(a.done, 1u);
+    }
+}
+
+template <typename T>
+struct LaCarryArgs
+{
+    int n, m_a, m_b;
+    const int* idf_b;
+    PredictArgs<T> pp_b;
+    const T *PH, *Dbb, *PvLb, *XLb; // blocks / rows kernels (XLb: landmark coordinates of b in the base state)
+    const LaModel<T>* model_a;
+    const T *Gt_a, *u_a, *M_a, *sub_a; // factor outputs of update a; sub_a rows 0..2 are PHT_a's pose rows
+    // outputs
+    T*          sub_b;  // (3 + kb) x kb
+    T*          xloc_b; // 3 + kb
+    LaModel<T>* model_b;
+    T*          Y_b;    // H_b * W1_a (kb x ka): Y_b[q*kb + row], the layout of ekf_gather_kernel's Yout
+};
+
+template <typename T>
+inline size_t la_carry_lds()
+{
+    constexpr int KM = 2 * kLaMaxObs, LD = KM + 4, LB = 3 + KM + 1;
+    return ((size_t)2 * KM * LD + (size_t)(3 + KM) * LB + kLaMaxObs * 10 + (3 + KM) + 4 * KM + 3 * KM) * sizeof(T) + 64;
+}
+
+// One workgroup of 256 threads between factor(a) and factor(b) (inside ekf_la_chain_kernel).  smem: la_carry_lds<T>() bytes.
+template <typename T>
+__device__ __forceinline__ void ekf_la_carry_body(const LaCarryArgs<T>& a, unsigned char* smem)
+{
+    constexpr int KM = 2 * kLaMaxObs; // 64
+    constexpr int LD = KM + 4;        // 16-byte aligned rows, conflict-free 16-byte reads
+    constexpr int LB = 3 + KM + 1;
+    T* pht  = reinterpret_cast<T*>(smem);    // pht[q*LD + s] = PHT_a[row s of b][q]
+    T* gm   = pht + KM * LD;                 // gm[q*LD + c]  = G_a(q, c); after the first product the SAME space holds
+    T* w1t  = gm;                            // w1t[c*LD + s] = W1_a[row s of b][c]
+    T* blk  = gm + KM * LD;                  // (3 + kb) square block of P in rows(b) order, row-major LB
+    T* coef = blk + (3 + KM) * LB;
+    T* xl   = coef + kLaMaxObs * 10;
+    T* ua   = xl + (3 + KM);                 // u_a (KM), M_a (3 x KM at ua + KM)
+    T* php  = ua + 4 * KM;                   // PHT_a pose rows (3 x ka)
+    __shared__ T s_pose[3], s_pvv[9], s_g[2];
+
+    const int tid = threadIdx.x;
+    const int ka = 2 * a.m_a, kb = 2 * a.m_b, mb = a.m_b;
+    const int ts = tid & 15, tc = tid >> 4;
+    const int s0 = 4 * ts, c0 = 4 * tc;
+
+    // ---- every global load up front
+    T rph[16], rg[16], rd[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+    {
+        const int e = tid + it * 256; // 64 x 64 padded index space: (row, col) = (e / 64, e % 64)
+        const int r = e >> 6, c = e & 63;
+        rph[it]     = (r < kb && c < ka) ? a.PH[(size_t)r * ka + c] : (T)0;
+        rg[it]      = (r < ka && c < ka) ? a.Gt_a[(size_t)r * ka + c] : (T)0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const int r = s0 + i, c = c0 + j;
+            rd[i * 4 + j] = (r < kb && c < kb) ? a.Dbb[(size_t)r * kb + c] : (T)0;
+        }
+    }
+    T   ru = (T)0, rm[3] = {(T)0, (T)0, (T)0}, rp[3] = {(T)0, (T)0, (T)0}, re[3] = {(T)0, (T)0, (T)0}, rx = (T)0;
+    int rrow = 0;
+    if (tid < ka)
+    {
+        ru    = a.u_a[tid];
+        rm[0] = a.M_a[tid], rm[1] = a.M_a[ka + tid], rm[2] = a.M_a[2 * ka + tid];
+        rp[0] = a.sub_a[tid], rp[1] = a.sub_a[ka + tid], rp[2] = a.sub_a[2 * ka + tid];
+    }
+    if (tid < kb)
+    {
+        re[0] = a.PvLb[tid * 3 + 0], re[1] = a.PvLb[tid * 3 + 1], re[2] = a.PvLb[tid * 3 + 2];
+        rx    = a.XLb[tid];
+        rrow  = la_row(a.idf_b, tid, a.n);
+    }
+    const LaModel<T>& ma_ = *a.model_a;
+    T                 mpose = (T)0, mpvv = (T)0;
+    if (tid < 3)
+    {
+        mpose = ma_.pose[tid];
+    }
+    if (tid < 9)
+    {
+        mpvv = ma_.pvv[tid];
+    }
+    // ---- park them in LDS
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+    {
+        const int e = tid + it * 256;
+        const int r = e >> 6, c = e & 63;
+        pht[c * LD + r] = rph[it]; // transposed: q = c
+        gm[r * LD + c]  = rg[it];
+    }
+    if (tid < KM)
+    {
+        ua[tid]          = ru;
+        ua[KM + tid]     = rm[0];
+        ua[2 * KM + tid] = rm[1];
+        ua[3 * KM + tid] = rm[2];
+        php[tid]          = rp[0];
+        php[KM + tid]     = rp[1];
+        php[2 * KM + tid] = rp[2];
+    }
+    __syncthreads();
+    // ---- W1_a[rows_lm(b)] = PHT_a[rows_lm(b)] * G_a on 4 x 4 register tiles
+    T acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        acc[e] = (T)0;
+    }
+    for (int q = 0; q < ka; q++)
+    {
+        T pa[4], pg[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            pa[i] = pht[q * LD + s0 + i];
+            pg[i] = gm[q * LD + c0 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                acc[i * 4 + j] += pa[i] * pg[j];
+            }
+        }
+    }
+    __syncthreads(); // (everybody is done reading G_a: its space takes the product)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            w1t[(c0 + j) * LD + s0 + i] = acc[i * 4 + j];
+        }
+    }
+    __syncthreads();
+    // ---- P[rows_lm(b), rows_lm(b)] = D_bb - W1 W1^T ((s, t) and (t, s): the same products in the same order)
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        acc[e] = (T)0;
+    }
+    for (int q = 0; q < ka; q++)
+    {
+        T pa[4], pb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            pa[i] = w1t[q * LD + s0 + i];
+            pb[i] = w1t[q * LD + c0 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                acc[i * 4 + j] += pa[i] * pb[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            blk[(3 + s0 + i) * LB + 3 + c0 + j] = rd[i * 4 + j] - acc[i * 4 + j];
+        }
+    }
+    // ---- stripe rows of b: -= PHT_a[row] M_a^T; landmark coordinates: += PHT_a[row] u_a
+    if (tid < kb)
+    {
+        T d0 = (T)0, d1 = (T)0, d2 = (T)0, xs = (T)0;
+        for (int q = 0; q < ka; q++)
+        {
+            const T p = pht[q * LD + tid];
+            d0 += p * ua[KM + q];
+            d1 += p * ua[2 * KM + q];
+            d2 += p * ua[3 * KM + q];
+            xs += p * ua[q];
+        }
+        blk[(3 + tid) * LB + 0] = re[0] - d0;
+        blk[(3 + tid) * LB + 1] = re[1] - d1;
+        blk[(3 + tid) * LB + 2] = re[2] - d2;
+        xl[3 + tid]             = rx + xs;
+    }
+    // the pose and the 3 x 3 pose block (the gain kernel's rule: the thread of the larger index applies its increment
+    // to both (r, c) and (c, r))
+    if (tid < 9)
+    {
+        s_pvv[tid] = mpvv;
+    }
+    __syncthreads();
+    if (tid < 3)
+    {
+        const int r = tid;
+        T         d[3] = {(T)0, (T)0, (T)0}, xs = (T)0;
+        for (int q = 0; q < ka; q++)
+        {
+            const T p = php[r * KM + q];
+            d[0] += p * ua[KM + q];
+            d[1] += p * ua[2 * KM + q];
+            d[2] += p * ua[3 * KM + q];
+            xs += p * ua[q];
+        }
+        s_pose[r] = mpose + xs;
+        T nv[3], nt[3]; // new (r, c) and new (c, r) for c < r
+        for (int c = 0; c < 3; c++)
+        {
+            nv[c] = s_pvv[r + 3 * c] - d[c];
+            nt[c] = s_pvv[c + 3 * r] - d[c];
+        }
+        // (each (r, c) pair is written by exactly one thread: r for c <= r)
+        for (int c = 0; c <= r; c++)
+        {
+            blk[r * LB + c] = nv[c];
+            if (c < r)
+            {
+                blk[c * LB + r] = nt[c];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- update b's own predict (EKF.cpp:406-455), held back by the engine
+    if (tid == 0)
+    {
+        T pvv_in[9], pose[3], g[2], pvv[9];
+        for (int e = 0; e < 9; e++)
+        {
+            pvv_in[e] = blk[(e % 3) * LB + e / 3];
+        }
+        la_predict_pose<T>(a.pp_b, s_pose, pvv_in, pose, g, pvv);
+        xl[0] = pose[0], xl[1] = pose[1], xl[2] = pose[2];
+        s_g[0] = g[0], s_g[1] = g[1];
+        for (int e = 0; e < 9; e++)
+        {
+            s_pvv[e]                  = pvv[e];
+            blk[(e % 3) * LB + e / 3] = pvv[e];
+        }
+    }
+    __syncthreads();
+    if (tid < kb)
+    {
+        T e3[3] = {blk[(3 + tid) * LB + 0], blk[(3 + tid) * LB + 1], blk[(3 + tid) * LB + 2]};
+        la_predict_row<T>(a.pp_b, s_g[0], s_g[1], rrow, e3);
+        for (int c = 0; c < 3; c++)
+        {
+            blk[(3 + tid) * LB + c] = e3[c]; // P[row, c]
+            blk[c * LB + 3 + tid]   = e3[c]; // P[c, row] (the stripe is stored once)
+        }
+    }
+    if (tid < mb)
+    {
+        T   v[2];
+        int fx;
+        observe_model_pose<T>(xl, 3 + kb, tid + 1, (T)0, (T)0, xl[0], xl[1], xl[2], &coef[tid * 10], v, &fx);
+    }
+    __syncthreads();
+    // ---- sub_b = PHT_b[rows(b), :], the five terms of ekf_gather_kernel in its order; Y_b = H_b * W1_a
+    for (int e = tid; e < (3 + kb) * mb; e += 256)
+    {
+        const int slot = e / mb, o = e % mb;
+        const T*  br   = &blk[slot * LB];
+        T         v0, v1;
+        la_pht_pair<T>(&coef[o * 10], br[0], br[1], br[2], br[3 + 2 * o], br[3 + 2 * o + 1], &v0, &v1);
+        a.sub_b[slot * kb + 2 * o]     = v0;
+        a.sub_b[slot * kb + 2 * o + 1] = v1;
+    }
+    for (int e = tid; e < ka * mb; e += 256)
+    {
+        const int q = e / mb, o = e % mb;
+        const T*  c = &coef[o * 10];
+        const T   wa = w1t[q * LD + 2 * o], wb = w1t[q * LD + 2 * o + 1];
+        T         y0 = c[3] * wa;
+        y0 += c[4] * wb;
+        T y1 = c[8] * wa;
+        y1 += c[9] * wb;
+        a.Y_b[(size_t)q * kb + 2 * o]     = y0;
+        a.Y_b[(size_t)q * kb + 2 * o + 1] = y1;
+    }
+    for (int e = tid; e < 3 + kb; e += 256)
+    {
+        a.xloc_b[e] = xl[e];
+    }
+    LaModel<T>& mo = *a.model_b;
+    if (tid == 0)
+    {
+        mo.g02 = s_g[0];
+        mo.g12 = s_g[1];
+    }
+    if (tid < 3)
+    {
+        mo.pose[tid] = xl[tid];
+    }
+    if (tid < 9)
+    {
+        mo.pvv[tid] = s_pvv[tid];
+    }
+    for (int e = tid; e < mb * 10; e += 256)
+    {
+        mo.coef[e] = coef[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The factor chain of one look-ahead window in ONE launch on stream F: factor(a), carry, factor(b).
+//   * It is launched BEFORE the window's rows / blocks kernels are even submitted to the main stream and waits for them
+//     on a counter in memory (the blocks kernel's workgroups count themselves out).  Being early is the point: the
+//     workgroup asks for so much LDS that it owns its compute unit, so the persistent P-GEMM that follows on the main
+//     stream (grid reduced by two workgroups) cannot share the unit -- next to its matrix-bound waves the chain runs four
+//     times slower (factor kernel: 83 us instead of 22), wave priority changes nothing, queue CU masks cost the P-GEMM
+//     14 % (the dispatcher deals workgroups to the shader engines evenly: an engine that lost a unit is short of two
+//     slots), and a unit vacated by P-GEMM workgroups is refilled by the dispatcher.
+//   * One launch, no events on the way in: the kernel boundaries and hand-overs of three launches cost ~20 us of stream F.
+// Same arithmetic as the three kernels launched one after another.  A wait that outlasts `timeout` (a host error path
+// that never submitted the blocks kernel) raises kFlagLaTimeout and goes on, so the grid always drains.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFlagLaTimeout = 16;
+
+template <typename T>
+struct LaChainArgs
+{
+    FactorArgs<T>   fa, fb;
+    T *             du_a, *du_b;
+    LaCarryArgs<T>  ca;
+    int             nu;     // updates in the window (1 or 2)
+    const unsigned* done;   // counter of the blocks kernels' workgroups
+    unsigned        target; // its value once this window's blocks kernel has finished
+    unsigned long long timeout; // in s_memrealtime ticks (100 MHz)
+};
+
+template <typename T, int K>
+__global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
+{
+    extern __shared__ __align__(16) unsigned char la_chain_smem[];
+    if (threadIdx.x == 0)
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int)(__hip_atomic_load(a.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.target) < 0)
+        {
+            __builtin_amdgcn_s_sleep(32);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout)
+            {
+                atomicOr(&a.fa.flags[0], kFlagLaTimeout);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence(); // acquire: the blocks kernel's rows
+    if constexpr (std::is_same<T, float>::value)
+    {
+        ekf_factor_mfma_f32_body<K>(a.fa, a.du_a);
+    }
+    else
+    {
+        ekf_factor_mfma_f64_body<K>(a.fa, a.du_a);
+    }
+    if (a.nu == 2)
+    {
+        __threadfence(); // factor(a)'s outputs -> the carry step (other threads of this workgroup read them)
+        __syncthreads();
+        ekf_la_carry_body<T>(a.ca, la_chain_smem);
+        __threadfence();
+        __syncthreads();
+        if constexpr (std::is_same<T, float>::value)
+        {
+            ekf_factor_mfma_f32_body<K>(a.fb, a.du_b);
+        }
+        else
+        {
+            ekf_factor_mfma_f64_body<K>(a.fb, a.du_b);
+        }
+    }
+}
+
+} // namespace cslam

@@ -44,6 +44,8 @@ extern "C" {
 #define CSLAM_FACTOR_FALLBACK 1 /* LLT of S failed; eigen "square root" taken (slam.h:425-429)        */
 #define CSLAM_FACTOR_ZEROED 2   /* factor or its inverse non-finite -> update was a no-op (slam.h:252-255, 431-434) */
 #define CSLAM_FACTOR_SKIPPED 4  /* async mode: LLT failed and the update was skipped (see set_sync_mode) */
+#define CSLAM_FACTOR_INTERNAL 16 /* an internal wait of the look-ahead factor chain timed out (must never happen; results of
+                                   that window are undefined) */
 #define CSLAM_FACTOR_BAD_IDF 8  /* cslam_ekf_update_device: a device-resident feature index was outside 1..N; the kernels
                                    clamped it (no out-of-bounds access), the update used the clamped index           */
 

@@ -878,6 +878,7 @@ SWITCHES = [
     {"CSLAM_PIPELINE": "1"},              # the two-stream engine
     {"CSLAM_PIPELINE": "1", "CSLAM_PGEMM_SPARE": "64"},
     {"CSLAM_XCD_QUEUES": "1"},
+    {"CSLAM_LOOKAHEAD": "1"},             # look-ahead windows forced on (default: only large f32 filters)
 ]
 
 
@@ -936,4 +937,85 @@ def test_every_engine_switch_gives_the_same_filter(gpu_required, monkeypatch, en
     nf_new = 3 + 2 * N
     M[nf_new:nf_new + 2, nf_new:nf_new + 2] = 0
     assert np.array_equal(M, M.T)
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirks", QUIRKS)
+def test_lookahead_windows_match_the_oracle(gpu_required, dtype, quirks, monkeypatch):
+    """Look-ahead windows (ekf_lookahead.hpp): asynchronous batch updates with a deferral window are issued two at a
+    time, the factor chain of both running ahead on its own stream from small blocks of P while the previous window's
+    P-GEMM sweeps the matrix.  Whole windows, a window of one (a state read between two updates), different batch sizes,
+    held / double predicts, a drain by augment and by a heading observation, host and device-resident inputs -- against
+    the oracle's plain sequence of choleskyUpdate calls (slam.h:235-266)."""
+    import torch
+
+    monkeypatch.setenv("CSLAM_LOOKAHEAD", "1")  # (by default only large f32 filters take this path)
+    N, extra = 420, 2
+    # REF_EXACT without a heading observation on every step stays healthy only while S is nearly block-diagonal (the
+    # reference's lower-Cholesky gain, SURVEY 2.1 #1/#3): a tiny pose covariance and weak correlations keep it so for
+    # the length of this test (checked with the oracle: all codes 0)
+    corr, pose_scale = (0.02, 1e-4) if quirks == REF_EXACT else (0.1, 1e-2)
+    X0, P0 = make_scenario(N, dtype, seed=2024, corr=corr, pose_scale=pose_scale)
+    eng = _engine(N, dtype, quirks, X0, P0, extra)
+    orc = OracleState(X0, P0, dtype, quirks, extra)
+    hi = OracleState(X0.astype(np.float64), P0.astype(np.float64), np.float64, quirks, extra)
+    eng.set_sync_mode(False)
+    eng.set_deferred(128)
+    Q = np.diag([0.18, 6e-4]).astype(dtype)
+    R = np.diag([0.08, 0.0024]).astype(dtype)
+    rng = np.random.default_rng(11)
+    keep = []
+
+    def pred(swa):
+        for s in (eng, orc, hi):
+            s.predict(83.33, swa, Q, 73.0, 0.01)
+
+    def upd(m, seed, device=False):
+        idf = (rng.permutation(N)[:m] + 1).astype(np.int32)
+        Z = make_obs(orc.x(), idf, dtype, seed=seed)
+        if device:
+            dZ = torch.from_numpy(np.ascontiguousarray(Z.reshape(-1, order="F"))).cuda()
+            dI = torch.from_numpy(idf).cuda()
+            torch.cuda.synchronize()
+            keep.extend([dZ, dI])
+            eng.update_device(dZ.data_ptr(), m, R, dI.data_ptr(), batch=True)
+        else:
+            eng.update(Z, R, idf, True)
+        c = orc.update(Z, R, idf, True)
+        hi.update(Z.astype(np.float64), R.astype(np.float64), idf, True)
+        return c
+
+    codes = []
+    for t in range(4):                      # two whole windows, predict held into each update
+        pred(0.02 * t)
+        codes.append(upd(32, t, device=(t % 2 == 0)))
+    pred(-0.01)
+    codes.append(upd(20, 10))               # first of a window ...
+    xa = eng.get_x()                        # ... drained alone by a state read
+    assert_close("X mid", xa, orc.x(), 4 * X_RTOL[np.dtype(dtype)], hi.x(), fair=8.0)
+    codes.append(upd(24, 11))               # no predict in front of this one
+    pred(0.03)
+    codes.append(upd(32, 12))
+    pred(0.01)
+    pred(0.015)                             # two predicts in a row
+    codes.append(upd(9, 13))                # k = 18
+    Zn = np.array([[280.0], [-0.3]], dtype=dtype)
+    eng.augment(Zn, R)                      # drains the queued update
+    orc.augment(Zn, R)
+    hi.augment(Zn.astype(np.float64), R.astype(np.float64))
+    pred(0.0)
+    codes.append(upd(30, 14))
+    pred(0.01)
+    for s in (eng, orc, hi):
+        s.observe_heading(float(hi.x()[2]) + 1e-4, True)   # a control step between the two updates of a would-be window
+    codes.append(upd(30, 15))
+    codes.append(upd(32, 16))
+    codes.append(upd(32, 17))
+    assert not any(codes) and eng.factor_status() == 0, codes
+    X, P = eng.get_state()
+    dt = np.dtype(dtype)
+    assert eng.n == orc.n
+    assert_close("lookahead X", X, orc.x(), 4 * X_RTOL[dt], hi.x(), fair=8.0)
+    assert_close("lookahead P", P, orc.p(), 4 * P_RTOL[dt], hi.p(), fair=8.0)
     eng.close()

@@ -131,6 +131,21 @@ def test_headline_path_ref_exact_healthy_5000_landmarks_8_steps(gpu_required):
     _compare("ref_exact healthy", (Xg, Pg, trg), (Xo, Po), (Xh, Ph), 1e-5, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("lookahead", ["0", "1"])
+def test_headline_path_with_and_without_lookahead_windows(gpu_required, monkeypatch, lookahead):
+    """(a) again at N = 5000 with the look-ahead windows forced off / on (ekf_lookahead.hpp; on is the default at this
+    size): both schedules are the same filter, against the oracle."""
+    from conan_slam_amd.synth import Workload
+
+    monkeypatch.setenv("CSLAM_LOOKAHEAD", lookahead)
+    w = Workload(5000, 32, np.float32)
+    Xg, Pg, trg, flags, inputs = _run_timed_path(w, TEXTBOOK, 6, 128, heading=False)
+    Xo, Po, codes = _run_oracle(w, np.float32, TEXTBOOK, inputs, heading=False)
+    assert codes == [0] * 6 and flags == 0, (codes, flags)
+    Xh, Ph, _ = _run_oracle(w, np.float64, TEXTBOOK, inputs, heading=False)
+    _compare("headline la=" + lookahead, (Xg, Pg, trg), (Xo, Po), (Xh, Ph), 1e-5, 1e-4, 1e-4)
+
+
 @pytest.mark.parametrize("quirks", [TEXTBOOK, REF_EXACT])
 def test_f64_bench_mode_1000_landmarks_deferred_8_steps(gpu_required, quirks):
     """(c) the f64 bench mode (BASELINE configs[1]): N = 1000, m = 32, deferral window 128, async + update_device,
