@@ -464,7 +464,12 @@ def ekf_main(args):
             "landmarks": N, "n": n, "obs_per_update": m, "k": k, "gain_algebra": args.quirks,
             "deferred_columns": args.defer,
             "engine": "two-stream pipelined (P-GEMM of update t under the chain of update t+1)"
-                      if os.environ.get("CSLAM_PIPELINE", "0") != "0" else "single stream",
+                      if os.environ.get("CSLAM_PIPELINE", "0") != "0" else
+                      ("look-ahead windows: two updates per window, their factor chain (one launch on its own stream) under "
+                       "the previous window's P-GEMM, one wide launch per window"
+                       if (os.environ.get("CSLAM_LOOKAHEAD", "-1") != "0" and args.dtype == "f32" and n >= 7000
+                           and args.defer >= 2 * k and not args.sequential) or os.environ.get("CSLAM_LOOKAHEAD") == "1"
+                       else "single stream"),
             "parallelism": f"replicas x{world} (no collective)",
             "baseline_config": "BASELINE.json configs[2]" if (N, args.dtype) == (5000, "f32") else
                                ("BASELINE.json configs[1]" if (N, args.dtype) == (1000, "f64") else "custom"),

@@ -1496,19 +1496,26 @@ struct Ekf : EkfBase
     int         la_cus = 0;        // compute units the persistent P-GEMM leaves to the chain kernel (0 until stream F exists)
     unsigned*   la_done   = nullptr; // device counter: workgroups of the blocks kernels that have finished
     unsigned    la_target = 0;       // its value once every blocks kernel launched so far has finished
+    unsigned    la_seq    = 0;       // windows whose chain kernel has been launched
 
-    // dynamic LDS of the chain kernel: the carry step's arrays; in f64 the factor body's arrays live in the same space
-    static size_t la_chain_lds()
+    // Dynamic LDS of the chain kernel <T, K>: the carry step's arrays (in f64 the factor body's arrays live in the same
+    // space), padded so that the workgroup's total LDS is ~99 KB: more than 96 KB keeps the persistent P-GEMM's 64 KB
+    // workgroups off its compute unit, less than 106 KB lets it start beside ONE workgroup of the wide kernel (54 KB) --
+    // a chain kernel that found no unit before the P-GEMM filled the chip must still be able to start while the wide
+    // kernel's workgroups wait for it.
+    static size_t la_chain_lds(int K)
     {
         size_t need = la_carry_lds<T>();
         if (sizeof(T) == 8)
         {
-            constexpr int K = 64;
             need = std::max(need, (size_t)(K * (K + 1) + (3 + K) * (K + 1) + (K / 2) * 10 + 6 * K) * sizeof(double) +
                                       (size_t)(K / 2 + 4) * sizeof(int) + 16);
+            return need;
         }
-        return std::max(need, (size_t)100 * 1024 - (sizeof(T) == 4 ? 54 * 1024 : 0)); // (enough to keep the unit to itself)
+        const size_t fixed = (K == 64) ? 53984 : 15008; // static LDS of ekf_la_chain_kernel<float, K> (tools/kernel_resources.py)
+        return std::max(need, (size_t)101 * 1024 - fixed);
     }
+    int         la_fused   = 1; // env CSLAM_LA_FUSED=0: gather + gain per update instead of the one wide launch (A/B)
     long long*  la_stamps  = nullptr; // CSLAM_LA_STAMPS=1: phase stamps of factor(a) underneath the P-GEMM (diagnostics)
     // what debug_last_update reads (the handle's workspace, or the factor slot of a window's last update)
     const T *dbgS = nullptr, *dbgGt = nullptr, *dbgV = nullptr;
@@ -1559,12 +1566,13 @@ struct Ekf : EkfBase
             la_cus = 1;
             CSLAM_HIP_TRY(hipEventCreateWithFlags(&ev_fb, hipEventDisableTiming));
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_la_chain_kernel<T, 32>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds()));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds(32)));
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_la_chain_kernel<T, 64>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds()));
-            CSLAM_HIP_TRY(hipMalloc(&la_done, sizeof(unsigned)));
-            CSLAM_HIP_TRY(hipMemset(la_done, 0, sizeof(unsigned)));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds(64)));
+            CSLAM_HIP_TRY(hipMalloc(&la_done, 2 * sizeof(unsigned))); // [0] blocks workgroups done, [1] chain windows done
+            CSLAM_HIP_TRY(hipMemset(la_done, 0, 2 * sizeof(unsigned)));
             la_target = 0;
+            la_seq    = 0;
             for (FactorOut& f : fo)
             {
                 CSLAM_HIP_TRY(hipMalloc(&f.S, (size_t)KM * (KM + 1) * sizeof(T)));
@@ -1585,6 +1593,10 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipMalloc(&la_Dbb, (size_t)KM * KM * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&la_Y, (size_t)KM * KM * sizeof(T)));
             CSLAM_HIP_TRY(hipMalloc(&la_model, 2 * sizeof(LaModel<T>)));
+            if (const char* fv = getenv("CSLAM_LA_FUSED"))
+            {
+                la_fused = atoi(fv) ? 1 : 0;
+            }
             if (getenv("CSLAM_LA_STAMPS"))
             {
                 CSLAM_HIP_TRY(hipMalloc(&la_stamps, 16 * sizeof(long long)));
@@ -1760,6 +1772,8 @@ struct Ekf : EkfBase
             ch.done = la_done;
             ch.target  = la_target + n_blocks;
             ch.timeout = 20000000ull; // 0.2 s of s_memrealtime ticks
+            ch.chain_done = la_done + 1;
+            ch.seq        = ++la_seq;
             LaCarryArgs<T>& ca = ch.ca;
             ca.n       = n;
             ca.m_a     = ua.m;
@@ -1781,11 +1795,11 @@ struct Ekf : EkfBase
             ca.Y_b     = la_Y;
             if (std::max(ka, kb) <= 32)
             {
-                hipLaunchKernelGGL((ekf_la_chain_kernel<T, 32>), dim3(1), dim3(256), la_chain_lds(), stream_f, ch);
+                hipLaunchKernelGGL((ekf_la_chain_kernel<T, 32>), dim3(1), dim3(256), la_chain_lds(32), stream_f, ch);
             }
             else
             {
-                hipLaunchKernelGGL((ekf_la_chain_kernel<T, 64>), dim3(1), dim3(256), la_chain_lds(), stream_f, ch);
+                hipLaunchKernelGGL((ekf_la_chain_kernel<T, 64>), dim3(1), dim3(256), la_chain_lds(64), stream_f, ch);
             }
             CSLAM_HIP_TRY(hipGetLastError());
             CSLAM_HIP_TRY(hipEventRecord(ev_fb, stream_f));
@@ -1795,7 +1809,7 @@ struct Ekf : EkfBase
         //    for the factor step.  (From here to the blocks launch nothing may fail: the chain kernel is waiting.)
         const T* Wp = wbase(wcur);
         hipLaunchKernelGGL(ekf_la_rows_kernel<T>, dim3(ka + kb), dim3(128), 0, stream, dX, dPv, ldp, n, ua.dIdf, ka,
-                           nu == 2 ? ub.dIdf : ua.dIdf, kb, Wp, ldp, kp, la_kpad, la_XL, la_PvL, la_WR);
+                           nu == 2 ? ub.dIdf : ua.dIdf, kb, Wp, ldp, kp, la_kpad, la_XL, la_PvL, la_WR, dFlags);
         LaPrepArgs<T> pa;
         pa.P       = dP;
         pa.ldp     = ldp;
@@ -1829,8 +1843,58 @@ struct Ekf : EkfBase
         {
             return rc;
         }
-        // 4. the wide kernels of both updates, factors known
-        if ((rc = la_wide(ua, fo[0], ev_fb)) || (nu == 2 && (rc = la_wide(ub, fo[1], nullptr))))
+        // 4. the wide half of both updates, factors known: ONE launch in f32 (ekf_la_wide_f32), gather + gain per update
+        //    otherwise (CSLAM_LA_FUSED=0: A/B)
+        bool fused = false;
+        if constexpr (std::is_same<T, float>::value)
+        {
+            if (la_fused)
+            {
+                fused = true;
+                LaWideArgs wa;
+                wa.chain_done = la_done + 1; // (waits for the chain kernel in the kernel: a stream event costs ~6 us here)
+                wa.seq        = la_seq;
+                wa.timeout    = 20000000ull;
+                wa.flags      = dFlags;
+                wa.P       = dP;
+                wa.ldp     = ldp;
+                wa.n       = n;
+                wa.lower   = lower;
+                wa.X       = dX;
+                wa.Pv      = dPv;
+                wa.nu      = nu;
+                wa.idf_a   = ua.dIdf;
+                wa.idf_b   = nu == 2 ? ub.dIdf : ua.dIdf;
+                wa.ma      = ua.m;
+                wa.mb      = nu == 2 ? ub.m : 0;
+                wa.valid_a = ua.pp.valid;
+                wa.valid_b = nu == 2 ? ub.pp.valid : 0;
+                wa.w_a     = ua.pp.w;
+                wa.w_b     = nu == 2 ? ub.pp.w : 0;
+                wa.model_a = la_model;
+                wa.model_b = la_model + 1;
+                wa.Gt_a    = fo[0].Gt;
+                wa.u_a     = fo[0].U;
+                wa.M_a     = fo[0].M;
+                wa.sub_a   = fo[0].sub;
+                wa.Gt_b    = fo[1].Gt;
+                wa.u_b     = fo[1].U;
+                wa.M_b     = fo[1].M;
+                wa.sub_b   = fo[1].sub;
+                wa.Y_b     = la_Y;
+                wa.W1a     = wbase(wcur) + (size_t)kp * ldp;
+                wa.W1b     = wa.W1a + (size_t)ka * ldp;
+                wa.ldw     = ldp;
+                wa.wv_out  = dWv;
+                hipLaunchKernelGGL(ekf_la_wide_f32, dim3(round_up(n, kTile) / 32), dim3(64), 0, stream, wa);
+                CSLAM_HIP_TRY(hipGetLastError());
+                last_slot = nullptr; // (PHT is not materialised on this path: nothing for debug_last_update)
+                last_k    = 0;
+                kp += ka + kb;
+                sub_valid = false;
+            }
+        }
+        if (!fused && ((rc = la_wide(ua, fo[0], ev_fb)) || (nu == 2 && (rc = la_wide(ub, fo[1], nullptr)))))
         {
             return rc;
         }

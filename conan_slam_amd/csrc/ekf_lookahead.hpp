@@ -54,9 +54,18 @@ __global__ void __launch_bounds__(128) ekf_la_rows_kernel(const T* __restrict__ 
                                                            const int* __restrict__ idf_a, int ra,
                                                            const int* __restrict__ idf_b, int rb,
                                                            const T* __restrict__ Wp, int ldw, int kp, int kpad,
-                                                           T* __restrict__ XL, T* __restrict__ PvL, T* __restrict__ WR)
+                                                           T* __restrict__ XL, T* __restrict__ PvL, T* __restrict__ WR,
+                                                           int* __restrict__ flags)
 {
     const int s   = blockIdx.x;
+    if (threadIdx.x == 4) // (device-resident feature ids cannot be checked by the host: clamped everywhere, flagged here)
+    {
+        const int id = (s < ra) ? idf_a[s >> 1] : idf_b[(s - ra) >> 1];
+        if (id < 1 || id > ((n - 3) >> 1))
+        {
+            atomicOr(&flags[0], kFlagBadIdf);
+        }
+    }
     const int row = (s < ra) ? la_row(idf_a, s, n) : la_row(idf_b, s - ra, n);
     for (int q = threadIdx.x; q < kp; q += 128)
     {
@@ -334,7 +343,7 @@ __global__ void __launch_bounds__(64) ekf_la_blocks_kernel(LaPrepArgs<T> a)
         }
     }
     // this workgroup's rows are out: release them to the chain kernel (device scope: it may run on another XCD)
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0)
     {
@@ -362,7 +371,7 @@ template <typename T>
 inline size_t la_carry_lds()
 {
     constexpr int KM = 2 * kLaMaxObs, LD = KM + 4, LB = 3 + KM + 1;
-    return ((size_t)2 * KM * LD + (size_t)(3 + KM) * LB + kLaMaxObs * 10 + (3 + KM) + 4 * KM + 3 * KM) * sizeof(T) + 64;
+    return ((size_t)KM * LD + (size_t)(3 + KM) * LB + kLaMaxObs * 10 + (3 + KM) + 4 * KM + 3 * KM) * sizeof(T) + 64;
 }
 
 // One workgroup of 256 threads between factor(a) and factor(b) (inside ekf_la_chain_kernel).  smem: la_carry_lds<T>() bytes.
@@ -372,11 +381,13 @@ __device__ __forceinline__ void ekf_la_carry_body(const LaCarryArgs<T>& a, unsig
     constexpr int KM = 2 * kLaMaxObs; // 64
     constexpr int LD = KM + 4;        // 16-byte aligned rows, conflict-free 16-byte reads
     constexpr int LB = 3 + KM + 1;
-    T* pht  = reinterpret_cast<T*>(smem);    // pht[q*LD + s] = PHT_a[row s of b][q]
-    T* gm   = pht + KM * LD;                 // gm[q*LD + c]  = G_a(q, c); after the first product the SAME space holds
+    // Two areas, each used twice (the carry step must fit beside a workgroup of the wide kernel on one compute unit,
+    // see ekf_la_chain_kernel):
+    T* pht  = reinterpret_cast<T*>(smem);    // pht[q*LD + s] = PHT_a[row s of b][q]; once the first product has read it:
+    T* blk  = pht;                           // the (3 + kb) square block of P in rows(b) order, row-major LB
+    T* gm   = pht + (3 + KM) * LB;           // gm[q*LD + c]  = G_a(q, c); after the first product the SAME space holds
     T* w1t  = gm;                            // w1t[c*LD + s] = W1_a[row s of b][c]
-    T* blk  = gm + KM * LD;                  // (3 + kb) square block of P in rows(b) order, row-major LB
-    T* coef = blk + (3 + KM) * LB;
+    T* coef = gm + KM * LD;
     T* xl   = coef + kLaMaxObs * 10;
     T* ua   = xl + (3 + KM);                 // u_a (KM), M_a (3 x KM at ua + KM)
     T* php  = ua + 4 * KM;                   // PHT_a pose rows (3 x ka)
@@ -451,6 +462,20 @@ __device__ __forceinline__ void ekf_la_carry_body(const LaCarryArgs<T>& a, unsig
         php[2 * KM + tid] = rp[2];
     }
     __syncthreads();
+    // ---- the sums that read PHT_a's rows (its LDS area is recycled below): stripe rows of b -= PHT_a[row] M_a^T,
+    //      landmark coordinates += PHT_a[row] u_a; the same for the three pose rows
+    T sd0 = (T)0, sd1 = (T)0, sd2 = (T)0, sxs = (T)0;
+    if (tid < kb)
+    {
+        for (int q = 0; q < ka; q++)
+        {
+            const T p = pht[q * LD + tid];
+            sd0 += p * ua[KM + q];
+            sd1 += p * ua[2 * KM + q];
+            sd2 += p * ua[3 * KM + q];
+            sxs += p * ua[q];
+        }
+    }
     // ---- W1_a[rows_lm(b)] = PHT_a[rows_lm(b)] * G_a on 4 x 4 register tiles
     T acc[16];
 #pragma unroll
@@ -522,22 +547,13 @@ __device__ __forceinline__ void ekf_la_carry_body(const LaCarryArgs<T>& a, unsig
             blk[(3 + s0 + i) * LB + 3 + c0 + j] = rd[i * 4 + j] - acc[i * 4 + j];
         }
     }
-    // ---- stripe rows of b: -= PHT_a[row] M_a^T; landmark coordinates: += PHT_a[row] u_a
+    // ---- stripe rows of b and landmark coordinates after update a (sums formed above)
     if (tid < kb)
     {
-        T d0 = (T)0, d1 = (T)0, d2 = (T)0, xs = (T)0;
-        for (int q = 0; q < ka; q++)
-        {
-            const T p = pht[q * LD + tid];
-            d0 += p * ua[KM + q];
-            d1 += p * ua[2 * KM + q];
-            d2 += p * ua[3 * KM + q];
-            xs += p * ua[q];
-        }
-        blk[(3 + tid) * LB + 0] = re[0] - d0;
-        blk[(3 + tid) * LB + 1] = re[1] - d1;
-        blk[(3 + tid) * LB + 2] = re[2] - d2;
-        xl[3 + tid]             = rx + xs;
+        blk[(3 + tid) * LB + 0] = re[0] - sd0;
+        blk[(3 + tid) * LB + 1] = re[1] - sd1;
+        blk[(3 + tid) * LB + 2] = re[2] - sd2;
+        xl[3 + tid]             = rx + sxs;
     }
     // the pose and the 3 x 3 pose block (the gain kernel's rule: the thread of the larger index applies its increment
     // to both (r, c) and (c, r))
@@ -682,6 +698,8 @@ struct LaChainArgs
     const unsigned* done;   // counter of the blocks kernels' workgroups
     unsigned        target; // its value once this window's blocks kernel has finished
     unsigned long long timeout; // in s_memrealtime ticks (100 MHz)
+    unsigned*       chain_done; // set to `seq` when the chain has finished (the wide kernel waits for it: no stream event)
+    unsigned        seq;
 };
 
 template <typename T, int K>
@@ -702,7 +720,7 @@ __global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
         }
     }
     __syncthreads();
-    __threadfence(); // acquire: the blocks kernel's rows
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // acquire: the blocks kernel's rows
     if constexpr (std::is_same<T, float>::value)
     {
         ekf_factor_mfma_f32_body<K>(a.fa, a.du_a);
@@ -713,11 +731,13 @@ __global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
     }
     if (a.nu == 2)
     {
-        __threadfence(); // factor(a)'s outputs -> the carry step (other threads of this workgroup read them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // factor(a)'s outputs -> the carry step (same workgroup)
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         ekf_la_carry_body<T>(a.ca, la_chain_smem);
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if constexpr (std::is_same<T, float>::value)
         {
             ekf_factor_mfma_f32_body<K>(a.fb, a.du_b);
@@ -725,6 +745,358 @@ __global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
         else
         {
             ekf_factor_mfma_f64_body<K>(a.fb, a.du_b);
+        }
+    }
+    // release the window's factors to the wide kernel on the main stream (device scope: other XCDs read them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        __hip_atomic_store(a.chain_done, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The WIDE half of a look-ahead window in ONE launch (f32): with the factors of both updates known, every block of 32
+// rows applies update a and update b to itself -- what ekf_gather_kernel + ekf_panel_mfma_f32 (+ the in-kernel
+// correction of the second gather) did in four launches:
+//   a:  PHT_a[rows] = P[rows, 0:3] HU_a^T + Ps[rows, lm(a)] LU_a^T      (slam.h:243, five non-zero columns of H per row;
+//                                                                         the predict of EKF.cpp:439-443 applied to the stripe)
+//       W1_a[rows]  = PHT_a[rows] G_a;  X[rows] += PHT_a[rows] u_a;  Pv[rows] -= PHT_a[rows] M_a^T      (slam.h:257-260)
+//   b:  PHT_b[rows] = P'[rows, 0:3] HU_b^T + Ps[rows, lm(b)] LU_b^T - W1_a[rows] Y_b^T     (Y_b = H_b W1_a from the carry step)
+//       W1_b[rows]  = PHT_b[rows] G_b;  X[rows] += ...;  Pv[rows] -= ...
+// Everything is row-local: the only cross-row quantities (H's coefficients at the updated state, Y_b, the pose rows of
+// PHT) come from the factor chain.  One wave per workgroup, 32 rows; the three n x 64 x 64 products run on
+// v_mfma_f32_32x32x2_f32 with the SAME operand layout throughout: a lane (row j = lane & 31, half h = lane >> 5) holds
+// entry q = 32 t' + (r & 3) + 8 (r >> 2) + 4 h of its row in register r of tile t' -- the accumulator layout -- and the
+// k-steps of the next product walk q in that order, so a product's result feeds the next one without a shuffle.
+// The pose rows (0..2) of PHT are the factor chain's (sub rows 0..2); their W1 entries are stored as zero and the pose
+// block follows the gain kernel's rule (the thread of the larger index applies its increment to both (r, c) and (c, r)).
+// grid = n_pad / 32 workgroups of 64 threads.
+// ------------------------------------------------------------------------------------------------
+struct LaWideArgs
+{
+    const float* P;
+    int          ldp, n, lower;
+    float*       X;
+    float*       Pv;
+    int          nu; // updates in the window
+    const int *  idf_a, *idf_b;
+    int          ma, mb;
+    int          valid_a, valid_b, w_a, w_b; // held predicts: valid, stripe width (n - 3, or n - 4 under REF_EXACT)
+    const LaModel<float>*model_a, *model_b;
+    const float *Gt_a, *u_a, *M_a, *sub_a;
+    const float *Gt_b, *u_b, *M_b, *sub_b, *Y_b;
+    float *      W1a, *W1b; // the two slots of the pending store
+    int          ldw;
+    float*       wv_out; // pose rows of the LAST update's W1 (3 x k), kept for the debug entry point
+    const unsigned* chain_done; // the chain kernel's completion word and the value this window waits for
+    unsigned        seq;
+    unsigned long long timeout;
+    int*            flags;
+};
+
+__device__ __forceinline__ int la_q_of(int t, int r, int lh)
+{
+    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+}
+
+__global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
+{
+    // The wave's work is one dependent chain, so every global read is issued as early as its address is known:
+    //   round 1: the small shared inputs, this row's stripe entries, and G_a^T, G_b^T, Y_b straight into LDS by LDS-DMA
+    //            (no registers in between: 16 KB each, one 1 KB piece per instruction);
+    //   round 2: the landmark columns of Ps for BOTH updates (their addresses need the feature ids of round 1).
+    // After that the kernel computes from registers and LDS only.
+    __shared__ __attribute__((aligned(16))) float s_G[2][4 * 1024]; // G^T of a / b, as in memory: [q * k + c]
+    __shared__ __attribute__((aligned(16))) float s_Y[4 * 1024];    // Y_b: [c * kb + q]
+    __shared__ float s_coef[2][kLaMaxObs * 10];
+    __shared__ int   s_fx[2][kLaMaxObs];
+    __shared__ float s_u[2][2 * kLaMaxObs];
+    __shared__ float s_M[2][3 * 2 * kLaMaxObs];
+    __shared__ float s_pred[2][14];
+    const int lane = threadIdx.x, lj = lane & 31, lh = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    const int row  = row0 + lj;
+    const int rowc = row < a.n ? row : a.n - 1;
+    const int ka = 2 * a.ma, kb = 2 * a.mb;
+    // the factor chain of this window (stream F) finished long ago in the steady state: one poll, no stream event
+    if (lane == 0)
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int)(__hip_atomic_load(a.chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.seq) < 0)
+        {
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout)
+            {
+                atomicOr(&a.flags[0], kFlagLaTimeout);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (acquire only: no write-back of this unit's L2)
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](const float* src, int count, float* dst) { // count floats, rounded up to whole 1 KB pieces (zeros beyond)
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (unsigned)(count * 4), 0x00020000);
+        for (int it = 0; it * 256 < count; it++)
+        {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + it * 256), 16, (unsigned)(lane * 16), (unsigned)(it * 1024),
+                                                     0, 0);
+        }
+    };
+    dma(a.Gt_a, ka * ka, s_G[0]);
+    if (a.nu == 2)
+    {
+        dma(a.Y_b, ka * kb, s_Y);
+        dma(a.Gt_b, kb * kb, s_G[1]);
+    }
+    // ---- small shared inputs
+    for (int e = lane; e < a.ma * 10; e += 64)
+    {
+        s_coef[0][e] = a.model_a->coef[e];
+    }
+    if (lane < a.ma)
+    {
+        s_fx[0][lane] = 3 + 2 * clamp_idf(a.idf_a[lane], a.n) - 2;
+    }
+    if (lane < ka)
+    {
+        s_u[0][lane] = a.u_a[lane];
+    }
+    for (int e = lane; e < 3 * ka; e += 64)
+    {
+        s_M[0][e] = a.M_a[e];
+    }
+    if (lane < 14)
+    {
+        s_pred[0][lane] = reinterpret_cast<const float*>(a.model_a)[lane];
+    }
+    if (a.nu == 2)
+    {
+        for (int e = lane; e < a.mb * 10; e += 64)
+        {
+            s_coef[1][e] = a.model_b->coef[e];
+        }
+        if (lane < a.mb)
+        {
+            s_fx[1][lane] = 3 + 2 * clamp_idf(a.idf_b[lane], a.n) - 2;
+        }
+        if (lane < kb)
+        {
+            s_u[1][lane] = a.u_b[lane];
+        }
+        for (int e = lane; e < 3 * kb; e += 64)
+        {
+            s_M[1][e] = a.M_b[e];
+        }
+        if (lane < 14)
+        {
+            s_pred[1][lane] = reinterpret_cast<const float*>(a.model_b)[lane];
+        }
+    }
+    float pv0 = a.Pv[(size_t)0 * a.ldp + rowc], pv1 = a.Pv[(size_t)1 * a.ldp + rowc], pv2 = a.Pv[(size_t)2 * a.ldp + rowc];
+    float x   = a.X[rowc];
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the DMA pieces have landed
+    __syncthreads();
+    // ---- round 2: the landmark columns of this lane's 16 observations, both updates
+    float pcol[2][32];
+#pragma unroll
+    for (int ub = 0; ub < 2; ub++)
+    {
+        const int k = ub == 0 ? ka : kb;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            const int  t = i >> 3, r = 2 * (i & 7);
+            const int  q = la_q_of(t, r, lh);
+            const int  o = q >> 1;
+            const bool in = q < k && (ub == 0 || a.nu == 2);
+            const int  fx = s_fx[ub][(in && o < kLaMaxObs) ? o : 0];
+            pcol[ub][2 * i]     = in ? p_sym<float>(a.P, a.ldp, rowc, fx, a.lower) : 0.f;
+            pcol[ub][2 * i + 1] = in ? p_sym<float>(a.P, a.ldp, rowc, fx + 1, a.lower) : 0.f;
+        }
+    }
+
+    f32x16 w1[2]; // W1 of the update in hand, accumulator layout (two column tiles)
+    float  pht[32];
+    float  xs = 0.f, xm0 = 0.f, xm1 = 0.f, xm2 = 0.f;
+
+    // PHT[row, :] of update `ub` (0 = a, 1 = b) in the accumulator layout; rows >= n give zeros, pose rows come from sub
+    auto build_pht = [&](auto UB, int k, const float* sub) {
+        constexpr int ub = decltype(UB)::value;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            const int   t = i >> 3, r = 2 * (i & 7);
+            const int   q = la_q_of(t, r, lh);
+            const int   o = (q >> 1) < kLaMaxObs ? (q >> 1) : 0;
+            const float* c = &s_coef[ub][o * 10];
+            float v0, v1;
+            la_pht_pair<float>(c, pv0, pv1, pv2, pcol[ub][2 * i], pcol[ub][2 * i + 1], &v0, &v1);
+            const bool in = (q < k) && (row < a.n);
+            if (row < 3 && in)
+            {
+                v0 = sub[row * k + q];
+                v1 = sub[row * k + q + 1];
+            }
+            pht[t * 16 + r]     = in ? v0 : 0.f;
+            pht[t * 16 + r + 1] = in ? v1 : 0.f;
+        }
+    };
+    // W1 = PHT * G on the matrix cores, and the row sums X += PHT u, Pv -= PHT M^T
+    auto gain = [&](auto UB, int k) {
+        constexpr int ub = decltype(UB)::value;
+        const float*  Gs = s_G[ub];
+        w1[0] = f32x16{0};
+        w1[1] = f32x16{0};
+        xs = xm0 = xm1 = xm2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int   q  = la_q_of(t, r, lh);
+                const int   qc = q < k ? q : 0;
+                const float g0 = (q < k && lj < k) ? Gs[qc * k + lj] : 0.f;
+                const float g1 = (q < k && 32 + lj < k) ? Gs[qc * k + 32 + lj] : 0.f;
+                const float b  = pht[t * 16 + r];
+                w1[0]          = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, b, w1[0], 0, 0, 0);
+                w1[1]          = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, b, w1[1], 0, 0, 0);
+                xs += b * s_u[ub][qc];
+                xm0 += b * s_M[ub][qc];
+                xm1 += b * s_M[ub][k + qc];
+                xm2 += b * s_M[ub][2 * k + qc];
+            }
+        }
+        xs += __shfl_xor(xs, 32);
+        xm0 += __shfl_xor(xm0, 32);
+        xm1 += __shfl_xor(xm1, 32);
+        xm2 += __shfl_xor(xm2, 32);
+    };
+    auto store_w1 = [&](float* W, int k, bool last) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int c = la_q_of(t, r, lh);
+                if (c < k)
+                {
+                    if (row < 3) // pose rows of the panel: kept aside, stored as zero (the stripe carries them)
+                    {
+                        if (last)
+                        {
+                            a.wv_out[(size_t)row * k + c] = w1[t][r];
+                        }
+                        W[(size_t)c * a.ldw + row] = 0.f;
+                    }
+                    else
+                    {
+                        W[(size_t)c * a.ldw + row] = w1[t][r];
+                    }
+                }
+            }
+        }
+    };
+
+    // ================= update a =================
+    if (a.valid_a && row >= 3 && row - 3 < a.w_a)
+    {
+        float o0, o1, o2;
+        predict_stripe_col<float>(s_pred[0][0], s_pred[0][1], pv0, pv1, pv2, &o0, &o1, &o2);
+        pv0 = o0, pv1 = o1, pv2 = o2;
+    }
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    build_pht(U0{}, ka, a.sub_a);
+    gain(U0{}, ka);
+    store_w1(a.W1a, ka, a.nu == 1);
+    const float* pred_last = s_pred[0];
+    if (a.nu == 2)
+    {
+        // state of the rows after update a (pose rows: the chain's values are taken at the end)
+        if (row >= 3)
+        {
+            x += xs;
+            pv0 -= xm0, pv1 -= xm1, pv2 -= xm2;
+        }
+        // ================= update b =================
+        if (a.valid_b && row >= 3 && row - 3 < a.w_b)
+        {
+            float o0, o1, o2;
+            predict_stripe_col<float>(s_pred[1][0], s_pred[1][1], pv0, pv1, pv2, &o0, &o1, &o2);
+            pv0 = o0, pv1 = o1, pv2 = o2;
+        }
+        const f32x16 wa0 = w1[0], wa1 = w1[1]; // W1_a[row, :], accumulator layout = the operand layout of the correction
+        build_pht(U1{}, kb, a.sub_b);
+        // PHT_b -= W1_a * Y_b^T : D[i = q][j = row] += Y_b[c][q] * W1_a[row][c] over c
+        f32x16 cr[2] = {f32x16{0}, f32x16{0}};
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int   c  = la_q_of(t, r, lh);
+                const int   cc = c < ka ? c : 0;
+                const float y0 = (c < ka && lj < kb) ? s_Y[cc * kb + lj] : 0.f;
+                const float y1 = (c < ka && 32 + lj < kb) ? s_Y[cc * kb + 32 + lj] : 0.f;
+                const float b  = (row >= 3) ? (t == 0 ? wa0[r] : wa1[r]) : 0.f; // (the panel's pose rows are zero)
+                cr[0]          = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, b, cr[0], 0, 0, 0);
+                cr[1]          = __builtin_amdgcn_mfma_f32_32x32x2f32(y1, b, cr[1], 0, 0, 0);
+            }
+        }
+        if (row >= 3)
+        {
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+            {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    pht[t * 16 + r] -= cr[t][r];
+                }
+            }
+        }
+        gain(U1{}, kb);
+        store_w1(a.W1b, kb, true);
+        pred_last = s_pred[1];
+    }
+    // ================= commit X and the stripe (the last update's sums are in xs / xm) =================
+    if (lh == 0 && row < a.n)
+    {
+        if (row >= 3)
+        {
+            a.X[row]                        = x + xs;
+            a.Pv[(size_t)0 * a.ldp + row] = pv0 - xm0;
+            a.Pv[(size_t)1 * a.ldp + row] = pv1 - xm1;
+            a.Pv[(size_t)2 * a.ldp + row] = pv2 - xm2;
+        }
+        else
+        {
+            // pose rows: start from the chain's predicted pose / pose block of the last update
+            const int   r     = row;
+            const float av[3] = {pred_last[5 + r], pred_last[5 + r + 3], pred_last[5 + r + 6]};
+            const float dv[3] = {xm0, xm1, xm2};
+            a.X[r]            = pred_last[2 + r] + xs;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+                if (c == r)
+                {
+                    a.Pv[(size_t)c * a.ldp + r] = av[c] - dv[c];
+                }
+                else if (c < r)
+                {
+                    const float bcr             = pred_last[5 + c + 3 * r]; // (c, r)
+                    a.Pv[(size_t)c * a.ldp + r] = av[c] - dv[c];
+                    a.Pv[(size_t)r * a.ldp + c] = bcr - dv[c];
+                }
+            }
         }
     }
 }

@@ -879,6 +879,7 @@ SWITCHES = [
     {"CSLAM_PIPELINE": "1", "CSLAM_PGEMM_SPARE": "64"},
     {"CSLAM_XCD_QUEUES": "1"},
     {"CSLAM_LOOKAHEAD": "1"},             # look-ahead windows forced on (default: only large f32 filters)
+    {"CSLAM_LOOKAHEAD": "1", "CSLAM_LA_FUSED": "0"},   # ... with gather + gain per update instead of the one wide launch
 ]
 
 
