@@ -1569,8 +1569,10 @@ struct Ekf : EkfBase
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds(32)));
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_la_chain_kernel<T, 64>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds(64)));
-            CSLAM_HIP_TRY(hipMalloc(&la_done, 2 * sizeof(unsigned))); // [0] blocks workgroups done, [1] chain windows done
-            CSLAM_HIP_TRY(hipMemset(la_done, 0, 2 * sizeof(unsigned)));
+            // words 0..255: 16 counters (stride 16) of finished blocks-kernel workgroups; words 256..767: 32 copies
+            // (stride 16) of the last window whose chain kernel has finished
+            CSLAM_HIP_TRY(hipMalloc(&la_done, 768 * sizeof(unsigned)));
+            CSLAM_HIP_TRY(hipMemset(la_done, 0, 768 * sizeof(unsigned)));
             la_target = 0;
             la_seq    = 0;
             for (FactorOut& f : fo)
@@ -1599,8 +1601,8 @@ struct Ekf : EkfBase
             }
             if (getenv("CSLAM_LA_STAMPS"))
             {
-                CSLAM_HIP_TRY(hipMalloc(&la_stamps, 16 * sizeof(long long)));
-                CSLAM_HIP_TRY(hipMemset(la_stamps, 0, 16 * sizeof(long long)));
+                CSLAM_HIP_TRY(hipMalloc(&la_stamps, 32 * sizeof(long long)));
+                CSLAM_HIP_TRY(hipMemset(la_stamps, 0, 32 * sizeof(long long)));
             }
         }
         if (kp_cols > la_kpad)
@@ -1611,7 +1613,7 @@ struct Ekf : EkfBase
             la_WR   = nullptr;
             la_kpad = 0;
             const int kpad = round_up(std::max(kp_cols, 128), 64);
-            CSLAM_HIP_TRY(hipMalloc(&la_WR, (size_t)2 * KM * kpad * sizeof(T)));
+            CSLAM_HIP_TRY(hipMalloc(&la_WR, (size_t)2 * KM * kpad * sizeof(T))); // [kpad columns][128 slots]
             la_kpad = kpad;
         }
         return CSLAM_OK;
@@ -1772,7 +1774,7 @@ struct Ekf : EkfBase
             ch.done = la_done;
             ch.target  = la_target + n_blocks;
             ch.timeout = 20000000ull; // 0.2 s of s_memrealtime ticks
-            ch.chain_done = la_done + 1;
+            ch.chain_done = la_done + 256;
             ch.seq        = ++la_seq;
             LaCarryArgs<T>& ca = ch.ca;
             ca.n       = n;
@@ -1852,14 +1854,15 @@ struct Ekf : EkfBase
             {
                 fused = true;
                 LaWideArgs wa;
-                wa.chain_done = la_done + 1; // (waits for the chain kernel in the kernel: a stream event costs ~6 us here)
+                wa.chain_done = la_done + 256; // (waits for the chain kernel in the kernel: a stream event costs ~6 us here)
                 wa.seq        = la_seq;
                 wa.timeout    = 20000000ull;
                 wa.flags      = dFlags;
+                wa.stamps     = la_stamps ? la_stamps + 16 : nullptr;
                 wa.P       = dP;
                 wa.ldp     = ldp;
                 wa.n       = n;
-                wa.lower   = lower;
+                wa.lower   = getenv("CSLAM_LA_TIMING_DIRECT") ? 0 : lower; // (timing experiment only: wrong results)
                 wa.X       = dX;
                 wa.Pv      = dPv;
                 wa.nu      = nu;
@@ -1902,9 +1905,12 @@ struct Ekf : EkfBase
         la_windows++;
         if (la_stamps && la_windows == 300)
         {
-            long long h[16];
+            long long h[32];
             CSLAM_HIP_TRY(hipStreamSynchronize(stream));
             CSLAM_HIP_TRY(hipMemcpy(h, la_stamps, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[cslam la wide stamps, 10 ns ticks] poll:%lld issue:%lld wait1:%lld pht_a(+round 2):%lld gain_a:%lld store_a:%lld pht_b:%lld corr:%lld gain_b:%lld store_b:%lld\n",
+                    h[17] - h[16], h[18] - h[17], h[19] - h[18], h[20] - h[19], h[21] - h[20], h[22] - h[21], h[23] - h[22],
+                    h[24] - h[23], h[25] - h[24], h[26] - h[25]);
             fprintf(stderr, "[cslam la stamps, cycles] load+observe:%lld sums:%lld symmetrise:%lld cholesky:%lld (first half %lld) inverse:%lld outputs:%lld total:%lld\n",
                     h[6] - h[0], h[7] - h[6], h[1] - h[7], h[2] - h[1], h[5] ? h[5] - h[1] : 0, h[3] - h[2], h[4] - h[3], h[4] - h[0]);
         }

@@ -46,7 +46,7 @@ __device__ inline int la_row(const int* __restrict__ idf, int s, int n)
 
 // ------------------------------------------------------------------------------------------------
 // rows: slot s < ra = 2 m_a belongs to update a, ra <= s < ra + rb to update b.
-//   XL[s] = X[row], PvL[s*3 + c] = Pv[c*ldp + row], WR[s*kpad + q] = Wp[q*ldw + row] (q < kp)
+//   XL[s] = X[row], PvL[s*3 + c] = Pv[c*ldp + row], WR[q*128 + s] = Wp[q*ldw + row] (q < kp; 128 slots per column)
 // grid = ra + rb workgroups of 128 threads.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(128) ekf_la_rows_kernel(const T* __restrict__ 
     const int row = (s < ra) ? la_row(idf_a, s, n) : la_row(idf_b, s - ra, n);
     for (int q = threadIdx.x; q < kp; q += 128)
     {
-        WR[(size_t)s * kpad + q] = Wp[(size_t)q * ldw + row];
+        WR[(size_t)q * 128 + s] = Wp[(size_t)q * ldw + row]; // slot-contiguous: the blocks kernel reads it lane = slot
     }
     if (threadIdx.x < 3)
     {
@@ -93,6 +93,7 @@ struct LaModel
     T pose[3];  // pose after the predict (EKF.cpp:445-452)
     T pvv[9];   // pose block after the predict, element (r, c) at r + 3c (EKF.cpp:430-440)
     T coef[kLaMaxObs * 10]; // H coefficients per observation (observe_model_pose)
+    T pad[2];               // (the struct is copied with 16-byte LDS-DMA pieces: 336 scalars)
 };
 
 // applies a held predict to one stripe row (row index `row` >= 3): Gv * (a0, a1, a2), EKF.cpp:442-443 with the n-4 quirk
@@ -166,7 +167,7 @@ struct LaPrepArgs
     LaModel<T>* model_a;
     T*   xloc_a; // 3 + ra
     int* idloc;  // 1 .. kLaMaxObs
-    unsigned* done; // counts finished workgroups (the chain kernel on stream F waits for this launch's share)
+    unsigned* done; // 16 counters (stride 16 words) of finished workgroups: the chain kernel on stream F waits for their sum
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(64) ekf_la_blocks_kernel(LaPrepArgs<T> a)
         row = la_row(idf_r, s, a.n);
         for (int q = tid; q < a.kp; q += 64) // (kp <= 256: the host keeps longer windows on the classic path)
         {
-            wrow[q] = a.WR[(size_t)wr_r * a.kpad + q];
+            wrow[q] = a.WR[(size_t)q * 128 + wr_r];
         }
         if (tid < nc)
         {
@@ -270,11 +271,26 @@ __global__ void __launch_bounds__(64) ekf_la_blocks_kernel(LaPrepArgs<T> a)
     }
     else if (tid < nc)
     {
-        const T* wc  = a.WR + (size_t)(wr_c0 + tid) * a.kpad;
+        const T* wc  = a.WR + wr_c0 + tid; // column q of the pending panels at this thread's slot: wc[q * 128]
         T        dot = (T)0;
-        for (int q = 0; q < a.kp; q++)
+        int      q   = 0;
+        for (; q + 8 <= a.kp; q += 8) // (eight loads in flight; the products are still added in ascending q)
         {
-            dot += wrow[q] * wc[q];
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                v[u] = wc[(size_t)(q + u) * 128];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                dot += wrow[q + u] * v[u];
+            }
+        }
+        for (; q < a.kp; q++)
+        {
+            dot += wrow[q] * wc[(size_t)q * 128];
         }
         s_d[tid] = pcell - dot;
     }
@@ -347,7 +363,7 @@ __global__ void __launch_bounds__(64) ekf_la_blocks_kernel(LaPrepArgs<T> a)
     __syncthreads();
     if (tid == 0)
     {
-        atomicAdd(a.done, 1u);
+        atomicAdd(a.done + 16 * (blockIdx.x & 15u), 1u); // (16 counters, 64 bytes apart: ~200 atomics on ONE word take ~5 us)
     }
 }
 
@@ -706,15 +722,30 @@ template <typename T, int K>
 __global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char la_chain_smem[];
-    if (threadIdx.x == 0)
+    if (threadIdx.x < 64) // (wave 0: lanes 0..15 read one counter each)
     {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((int)(__hip_atomic_load(a.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.target) < 0)
+        while (true)
         {
+            unsigned c = threadIdx.x < 16
+                             ? __hip_atomic_load(a.done + 16 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : 0u;
+            c += __shfl_xor(c, 1);
+            c += __shfl_xor(c, 2);
+            c += __shfl_xor(c, 4);
+            c += __shfl_xor(c, 8);
+            c = __shfl(c, 0);
+            if ((int)(c - a.target) >= 0)
+            {
+                break;
+            }
             __builtin_amdgcn_s_sleep(32);
             if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout)
             {
-                atomicOr(&a.fa.flags[0], kFlagLaTimeout);
+                if (threadIdx.x == 0)
+                {
+                    atomicOr(&a.fa.flags[0], kFlagLaTimeout);
+                }
                 break;
             }
         }
@@ -750,9 +781,9 @@ __global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
     // release the window's factors to the wide kernel on the main stream (device scope: other XCDs read them)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x < 32) // (32 copies, 64 bytes apart: the wide kernel's workgroups poll different words)
     {
-        __hip_atomic_store(a.chain_done, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.chain_done + 16 * threadIdx.x, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -794,6 +825,7 @@ struct LaWideArgs
     unsigned        seq;
     unsigned long long timeout;
     int*            flags;
+    long long*      stamps; // diagnostics (CSLAM_LA_STAMPS): s_memrealtime at phase boundaries of workgroup 100, or nullptr
 };
 
 __device__ __forceinline__ int la_q_of(int t, int r, int lh)
@@ -810,21 +842,29 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
     // After that the kernel computes from registers and LDS only.
     __shared__ __attribute__((aligned(16))) float s_G[2][4 * 1024]; // G^T of a / b, as in memory: [q * k + c]
     __shared__ __attribute__((aligned(16))) float s_Y[4 * 1024];    // Y_b: [c * kb + q]
-    __shared__ float s_coef[2][kLaMaxObs * 10];
-    __shared__ int   s_fx[2][kLaMaxObs];
-    __shared__ float s_u[2][2 * kLaMaxObs];
-    __shared__ float s_M[2][3 * 2 * kLaMaxObs];
-    __shared__ float s_pred[2][14];
+    __shared__ __attribute__((aligned(16))) float s_model[2][512]; // LaModel image: {g02, g12, pose, pvv} then coef at 14
+    __shared__ __attribute__((aligned(16))) float s_u[2][256];
+    __shared__ __attribute__((aligned(16))) float s_M[2][256];
+    __shared__ int s_fx[2][kLaMaxObs];
     const int lane = threadIdx.x, lj = lane & 31, lh = lane >> 5;
     const int row0 = blockIdx.x * 32;
     const int row  = row0 + lj;
     const int rowc = row < a.n ? row : a.n - 1;
     const int ka = 2 * a.ma, kb = 2 * a.mb;
+    int       stamp_i = 0;
+    auto      stamp   = [&]() {
+        if (a.stamps != nullptr && blockIdx.x == 100 && lane == 0)
+        {
+            a.stamps[stamp_i++] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+    };
+    stamp();
     // the factor chain of this window (stream F) finished long ago in the steady state: one poll, no stream event
     if (lane == 0)
     {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((int)(__hip_atomic_load(a.chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.seq) < 0)
+        const unsigned* word = a.chain_done + 16 * (blockIdx.x & 31u); // (313 polls of ONE word take ~7 us: 32 copies)
+        while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.seq) < 0)
         {
             __builtin_amdgcn_s_sleep(8);
             if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout)
@@ -840,8 +880,13 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
     auto dma = [&](const float* src, int count, float* dst) { // count floats, rounded up to whole 1 KB pieces (zeros beyond)
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (unsigned)(count * 4), 0x00020000);
-        for (int it = 0; it * 256 < count; it++)
+        const int pieces = (count + 255) / 256;
+        int       it     = (int)(blockIdx.x & 15u);
+        it               = it < pieces ? it : 0;
+        for (int j = 0; j < pieces; j++, it = (it + 1 < pieces) ? it + 1 : 0)
         {
+            // (every workgroup stages the same 16 KB: each starts at a different piece, so they do not walk the L2
+            // channels in step)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + it * 256), 16, (unsigned)(lane * 16), (unsigned)(it * 1024),
                                                      0, 0);
         }
@@ -852,56 +897,42 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
         dma(a.Y_b, ka * kb, s_Y);
         dma(a.Gt_b, kb * kb, s_G[1]);
     }
-    // ---- small shared inputs
-    for (int e = lane; e < a.ma * 10; e += 64)
-    {
-        s_coef[0][e] = a.model_a->coef[e];
-    }
-    if (lane < a.ma)
-    {
-        s_fx[0][lane] = 3 + 2 * clamp_idf(a.idf_a[lane], a.n) - 2;
-    }
-    if (lane < ka)
-    {
-        s_u[0][lane] = a.u_a[lane];
-    }
-    for (int e = lane; e < 3 * ka; e += 64)
-    {
-        s_M[0][e] = a.M_a[e];
-    }
-    if (lane < 14)
-    {
-        s_pred[0][lane] = reinterpret_cast<const float*>(a.model_a)[lane];
-    }
+    // ---- small shared inputs: by LDS-DMA as well (a load-then-store loop would cost a round trip per trip)
+    dma(reinterpret_cast<const float*>(a.model_a), 336, s_model[0]);
+    dma(a.u_a, ka, s_u[0]);
+    dma(a.M_a, 3 * ka, s_M[0]);
     if (a.nu == 2)
     {
-        for (int e = lane; e < a.mb * 10; e += 64)
-        {
-            s_coef[1][e] = a.model_b->coef[e];
-        }
-        if (lane < a.mb)
-        {
-            s_fx[1][lane] = 3 + 2 * clamp_idf(a.idf_b[lane], a.n) - 2;
-        }
-        if (lane < kb)
-        {
-            s_u[1][lane] = a.u_b[lane];
-        }
-        for (int e = lane; e < 3 * kb; e += 64)
-        {
-            s_M[1][e] = a.M_b[e];
-        }
-        if (lane < 14)
-        {
-            s_pred[1][lane] = reinterpret_cast<const float*>(a.model_b)[lane];
-        }
+        dma(reinterpret_cast<const float*>(a.model_b), 336, s_model[1]);
+        dma(a.u_b, kb, s_u[1]);
+        dma(a.M_b, 3 * kb, s_M[1]);
     }
+    const int id_a = lane < a.ma ? a.idf_a[lane] : 1;
+    const int id_b = (a.nu == 2 && lane < a.mb) ? a.idf_b[lane] : 1;
     float pv0 = a.Pv[(size_t)0 * a.ldp + rowc], pv1 = a.Pv[(size_t)1 * a.ldp + rowc], pv2 = a.Pv[(size_t)2 * a.ldp + rowc];
     float x   = a.X[rowc];
+    stamp();
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the DMA pieces have landed
+    if (lane < kLaMaxObs)
+    {
+        s_fx[0][lane] = 3 + 2 * clamp_idf(id_a, a.n) - 2;
+        s_fx[1][lane] = 3 + 2 * clamp_idf(id_b, a.n) - 2;
+    }
     __syncthreads();
+    stamp();
     // ---- round 2: the landmark columns of this lane's 16 observations, both updates
     float pcol[2][32];
+    int   fxv[2][16];
+#pragma unroll
+    for (int ub = 0; ub < 2; ub++) // (all the LDS reads first, then every global load back to back)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            const int o = la_q_of(i >> 3, 2 * (i & 7), lh) >> 1;
+            fxv[ub][i]  = s_fx[ub][o < kLaMaxObs ? o : 0];
+        }
+    }
 #pragma unroll
     for (int ub = 0; ub < 2; ub++)
     {
@@ -909,13 +940,14 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
 #pragma unroll
         for (int i = 0; i < 16; i++)
         {
-            const int  t = i >> 3, r = 2 * (i & 7);
-            const int  q = la_q_of(t, r, lh);
-            const int  o = q >> 1;
+            const int  q  = la_q_of(i >> 3, 2 * (i & 7), lh);
             const bool in = q < k && (ub == 0 || a.nu == 2);
-            const int  fx = s_fx[ub][(in && o < kLaMaxObs) ? o : 0];
-            pcol[ub][2 * i]     = in ? p_sym<float>(a.P, a.ldp, rowc, fx, a.lower) : 0.f;
-            pcol[ub][2 * i + 1] = in ? p_sym<float>(a.P, a.ldp, rowc, fx + 1, a.lower) : 0.f;
+            const int  fx = in ? fxv[ub][i] : 3;
+            // (unconditional loads, the VALUE is selected: a branch per load would serialise them)
+            const float va = p_sym<float>(a.P, a.ldp, rowc, fx, a.lower);
+            const float vb = p_sym<float>(a.P, a.ldp, rowc, fx + 1, a.lower);
+            pcol[ub][2 * i]     = in ? va : 0.f;
+            pcol[ub][2 * i + 1] = in ? vb : 0.f;
         }
     }
 
@@ -932,7 +964,7 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
             const int   t = i >> 3, r = 2 * (i & 7);
             const int   q = la_q_of(t, r, lh);
             const int   o = (q >> 1) < kLaMaxObs ? (q >> 1) : 0;
-            const float* c = &s_coef[ub][o * 10];
+            const float* c = &s_model[ub][14 + o * 10];
             float v0, v1;
             la_pht_pair<float>(c, pv0, pv1, pv2, pcol[ub][2 * i], pcol[ub][2 * i + 1], &v0, &v1);
             const bool in = (q < k) && (row < a.n);
@@ -1007,15 +1039,18 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
     if (a.valid_a && row >= 3 && row - 3 < a.w_a)
     {
         float o0, o1, o2;
-        predict_stripe_col<float>(s_pred[0][0], s_pred[0][1], pv0, pv1, pv2, &o0, &o1, &o2);
+        predict_stripe_col<float>(s_model[0][0], s_model[0][1], pv0, pv1, pv2, &o0, &o1, &o2);
         pv0 = o0, pv1 = o1, pv2 = o2;
     }
     using U0 = std::integral_constant<int, 0>;
     using U1 = std::integral_constant<int, 1>;
     build_pht(U0{}, ka, a.sub_a);
+    stamp();
     gain(U0{}, ka);
+    stamp();
     store_w1(a.W1a, ka, a.nu == 1);
-    const float* pred_last = s_pred[0];
+    stamp();
+    const float* pred_last = s_model[0];
     if (a.nu == 2)
     {
         // state of the rows after update a (pose rows: the chain's values are taken at the end)
@@ -1028,11 +1063,12 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
         if (a.valid_b && row >= 3 && row - 3 < a.w_b)
         {
             float o0, o1, o2;
-            predict_stripe_col<float>(s_pred[1][0], s_pred[1][1], pv0, pv1, pv2, &o0, &o1, &o2);
+            predict_stripe_col<float>(s_model[1][0], s_model[1][1], pv0, pv1, pv2, &o0, &o1, &o2);
             pv0 = o0, pv1 = o1, pv2 = o2;
         }
         const f32x16 wa0 = w1[0], wa1 = w1[1]; // W1_a[row, :], accumulator layout = the operand layout of the correction
         build_pht(U1{}, kb, a.sub_b);
+        stamp();
         // PHT_b -= W1_a * Y_b^T : D[i = q][j = row] += Y_b[c][q] * W1_a[row][c] over c
         f32x16 cr[2] = {f32x16{0}, f32x16{0}};
 #pragma unroll
@@ -1062,9 +1098,12 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
                 }
             }
         }
+        stamp();
         gain(U1{}, kb);
+        stamp();
         store_w1(a.W1b, kb, true);
-        pred_last = s_pred[1];
+        stamp();
+        pred_last = s_model[1];
     }
     // ================= commit X and the stripe (the last update's sums are in xs / xm) =================
     if (lh == 0 && row < a.n)
