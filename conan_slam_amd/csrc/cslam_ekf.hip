@@ -1889,7 +1889,7 @@ struct Ekf : EkfBase
                 wa.W1b     = wa.W1a + (size_t)ka * ldp;
                 wa.ldw     = ldp;
                 wa.wv_out  = dWv;
-                hipLaunchKernelGGL(ekf_la_wide_f32, dim3(round_up(n, kTile) / 32), dim3(64), 0, stream, wa);
+                hipLaunchKernelGGL(ekf_la_wide_f32, dim3(round_up(n, kTile) / 32), dim3(128), 0, stream, wa);
                 CSLAM_HIP_TRY(hipGetLastError());
                 last_slot = nullptr; // (PHT is not materialised on this path: nothing for debug_last_update)
                 last_k    = 0;
@@ -1908,9 +1908,9 @@ struct Ekf : EkfBase
             long long h[32];
             CSLAM_HIP_TRY(hipStreamSynchronize(stream));
             CSLAM_HIP_TRY(hipMemcpy(h, la_stamps, sizeof(h), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[cslam la wide stamps, 10 ns ticks] poll:%lld issue:%lld wait1:%lld pht_a(+round 2):%lld gain_a:%lld store_a:%lld pht_b:%lld corr:%lld gain_b:%lld store_b:%lld\n",
+            fprintf(stderr, "[cslam la wide stamps, 10 ns ticks] ids+columns issue:%lld poll+DMA wait:%lld pht_a:%lld gain_a:%lld store+share W1_a:%lld pht_b+corr:%lld share+G_b:%lld gain_b:%lld store_b:%lld\n",
                     h[17] - h[16], h[18] - h[17], h[19] - h[18], h[20] - h[19], h[21] - h[20], h[22] - h[21], h[23] - h[22],
-                    h[24] - h[23], h[25] - h[24], h[26] - h[25]);
+                    h[24] - h[23], h[25] - h[24]);
             fprintf(stderr, "[cslam la stamps, cycles] load+observe:%lld sums:%lld symmetrise:%lld cholesky:%lld (first half %lld) inverse:%lld outputs:%lld total:%lld\n",
                     h[6] - h[0], h[7] - h[6], h[1] - h[7], h[2] - h[1], h[5] ? h[5] - h[1] : 0, h[3] - h[2], h[4] - h[3], h[4] - h[0]);
         }

@@ -797,13 +797,13 @@ __global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
 //   b:  PHT_b[rows] = P'[rows, 0:3] HU_b^T + Ps[rows, lm(b)] LU_b^T - W1_a[rows] Y_b^T     (Y_b = H_b W1_a from the carry step)
 //       W1_b[rows]  = PHT_b[rows] G_b;  X[rows] += ...;  Pv[rows] -= ...
 // Everything is row-local: the only cross-row quantities (H's coefficients at the updated state, Y_b, the pose rows of
-// PHT) come from the factor chain.  One wave per workgroup, 32 rows; the three n x 64 x 64 products run on
+// PHT) come from the factor chain.  Two waves per workgroup, 32 rows; the three n x 64 x 64 products run on
 // v_mfma_f32_32x32x2_f32 with the SAME operand layout throughout: a lane (row j = lane & 31, half h = lane >> 5) holds
 // entry q = 32 t' + (r & 3) + 8 (r >> 2) + 4 h of its row in register r of tile t' -- the accumulator layout -- and the
 // k-steps of the next product walk q in that order, so a product's result feeds the next one without a shuffle.
 // The pose rows (0..2) of PHT are the factor chain's (sub rows 0..2); their W1 entries are stored as zero and the pose
 // block follows the gain kernel's rule (the thread of the larger index applies its increment to both (r, c) and (c, r)).
-// grid = n_pad / 32 workgroups of 64 threads.
+// grid = n_pad / 32 workgroups of 128 threads.
 // ------------------------------------------------------------------------------------------------
 struct LaWideArgs
 {
@@ -833,37 +833,87 @@ __device__ __forceinline__ int la_q_of(int t, int r, int lh)
     return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
 }
 
-__global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
+__global__ void __launch_bounds__(128) ekf_la_wide_f32(LaWideArgs a)
 {
-    // The wave's work is one dependent chain, so every global read is issued as early as its address is known:
-    //   round 1: the small shared inputs, this row's stripe entries, and G_a^T, G_b^T, Y_b straight into LDS by LDS-DMA
-    //            (no registers in between: 16 KB each, one 1 KB piece per instruction);
+    // TWO waves per block of 32 rows.  Wave w owns column tile w (32 columns) of every product -- half the matrix-core
+    // chain, half the operand reads -- and builds tile w of PHT; the halves meet through LDS (one 8 KB exchange area,
+    // carved out of the G areas while they are not in use).  The wave's work is one dependent chain, so every global
+    // read is issued as early as its address is known:
+    //   round 1: the small shared inputs, this row's stripe entries, and G_a^T, Y_b straight into LDS by LDS-DMA
+    //            (no registers in between: 16 KB each, one 1 KB piece per instruction); G_b^T follows once the exchange
+    //            area has moved out of its space;
     //   round 2: the landmark columns of Ps for BOTH updates (their addresses need the feature ids of round 1).
     // After that the kernel computes from registers and LDS only.
     __shared__ __attribute__((aligned(16))) float s_G[2][4 * 1024]; // G^T of a / b, as in memory: [q * k + c]
     __shared__ __attribute__((aligned(16))) float s_Y[4 * 1024];    // Y_b: [c * kb + q]
-    __shared__ __attribute__((aligned(16))) float s_model[2][512]; // LaModel image: {g02, g12, pose, pvv} then coef at 14
+    __shared__ __attribute__((aligned(16))) float s_model[2][512];  // LaModel image: {g02, g12, pose, pvv} then coef at 14
     __shared__ __attribute__((aligned(16))) float s_u[2][256];
     __shared__ __attribute__((aligned(16))) float s_M[2][256];
-    __shared__ int s_fx[2][kLaMaxObs];
-    const int lane = threadIdx.x, lj = lane & 31, lh = lane >> 5;
+    __shared__ int   s_fx[2][kLaMaxObs];
+    __shared__ float s_sum[4][32];
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lj = lane & 31, lh = lane >> 5;
     const int row0 = blockIdx.x * 32;
     const int row  = row0 + lj;
     const int rowc = row < a.n ? row : a.n - 1;
     const int ka = 2 * a.ma, kb = 2 * a.mb;
     int       stamp_i = 0;
     auto      stamp   = [&]() {
-        if (a.stamps != nullptr && blockIdx.x == 100 && lane == 0)
+        if (a.stamps != nullptr && blockIdx.x == 100 && tid == 0)
         {
             a.stamps[stamp_i++] = (long long)__builtin_amdgcn_s_memrealtime();
         }
     };
     stamp();
-    // the factor chain of this window (stream F) finished long ago in the steady state: one poll, no stream event
-    if (lane == 0)
+    // ---- round 0: what does not come from the factor chain is requested before the chain is waited for: the feature ids,
+    //      this row's stripe entries and state entry ...
+    const int id_a = lane < a.ma ? a.idf_a[lane] : 1;
+    const int id_b = (a.nu == 2 && lane < a.mb) ? a.idf_b[lane] : 1;
+    float pv0 = a.Pv[(size_t)0 * a.ldp + rowc], pv1 = a.Pv[(size_t)1 * a.ldp + rowc], pv2 = a.Pv[(size_t)2 * a.ldp + rowc];
+    float x   = a.X[rowc];
+    if (tid < kLaMaxObs)
     {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned* word = a.chain_done + 16 * (blockIdx.x & 31u); // (313 polls of ONE word take ~7 us: 32 copies)
+        s_fx[0][tid] = 3 + 2 * clamp_idf(id_a, a.n) - 2;
+        s_fx[1][tid] = 3 + 2 * clamp_idf(id_b, a.n) - 2;
+    }
+    __syncthreads();
+    // ---- ... and the landmark columns of Ps of this wave's tile (8 observations per lane), both updates
+    float pcol[2][16];
+    {
+        int fxv[2][8];
+#pragma unroll
+        for (int ub = 0; ub < 2; ub++) // (all the LDS reads first, then every global load back to back)
+        {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                const int o = (32 * wv + (2 * i & 3) + 8 * (2 * i >> 2) + 4 * lh) >> 1;
+                fxv[ub][i]  = s_fx[ub][o < kLaMaxObs ? o : 0];
+            }
+        }
+#pragma unroll
+        for (int ub = 0; ub < 2; ub++)
+        {
+            const int k = ub == 0 ? ka : kb;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                const int  q  = 32 * wv + (2 * i & 3) + 8 * (2 * i >> 2) + 4 * lh;
+                const bool in = q < k && (ub == 0 || a.nu == 2);
+                const int  fx = in ? fxv[ub][i] : 3;
+                // (unconditional loads, the VALUE is selected: a branch per load would serialise them)
+                const float va = p_sym<float>(a.P, a.ldp, rowc, fx, a.lower);
+                const float vb = p_sym<float>(a.P, a.ldp, rowc, fx + 1, a.lower);
+                pcol[ub][2 * i]     = in ? va : 0.f;
+                pcol[ub][2 * i + 1] = in ? vb : 0.f;
+            }
+        }
+    }
+    stamp();
+    // ---- the factor chain of this window (stream F) finished long ago in the steady state: one poll, no stream event
+    if (tid == 0)
+    {
+        const unsigned long long t0   = __builtin_amdgcn_s_memrealtime();
+        const unsigned*          word = a.chain_done + 16 * (blockIdx.x & 31u);
         while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.seq) < 0)
         {
             __builtin_amdgcn_s_sleep(8);
@@ -876,8 +926,11 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (acquire only: no write-back of this unit's L2)
+    // ---- round 1: the chain's outputs straight into LDS by LDS-DMA
     typedef __attribute__((address_space(3))) void* lptr_t;
-    auto dma = [&](const float* src, int count, float* dst) { // count floats, rounded up to whole 1 KB pieces (zeros beyond)
+    // count floats, whole 1 KB pieces (zeros beyond); the two waves take alternate pieces, every workgroup starts at a
+    // different piece (they all stage the same 16 KB: this way they do not walk the L2 channels in step)
+    auto dma = [&](const float* src, int count, float* dst) {
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (unsigned)(count * 4), 0x00020000);
         const int pieces = (count + 255) / 256;
@@ -885,87 +938,59 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
         it               = it < pieces ? it : 0;
         for (int j = 0; j < pieces; j++, it = (it + 1 < pieces) ? it + 1 : 0)
         {
-            // (every workgroup stages the same 16 KB: each starts at a different piece, so they do not walk the L2
-            // channels in step)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + it * 256), 16, (unsigned)(lane * 16), (unsigned)(it * 1024),
-                                                     0, 0);
+            if ((j & 1) == wv)
+            {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + it * 256), 16, (unsigned)(lane * 16),
+                                                         (unsigned)(it * 1024), 0, 0);
+            }
         }
     };
     dma(a.Gt_a, ka * ka, s_G[0]);
-    if (a.nu == 2)
-    {
-        dma(a.Y_b, ka * kb, s_Y);
-        dma(a.Gt_b, kb * kb, s_G[1]);
-    }
-    // ---- small shared inputs: by LDS-DMA as well (a load-then-store loop would cost a round trip per trip)
     dma(reinterpret_cast<const float*>(a.model_a), 336, s_model[0]);
     dma(a.u_a, ka, s_u[0]);
     dma(a.M_a, 3 * ka, s_M[0]);
     if (a.nu == 2)
     {
+        dma(a.Y_b, ka * kb, s_Y);
         dma(reinterpret_cast<const float*>(a.model_b), 336, s_model[1]);
         dma(a.u_b, kb, s_u[1]);
         dma(a.M_b, 3 * kb, s_M[1]);
     }
-    const int id_a = lane < a.ma ? a.idf_a[lane] : 1;
-    const int id_b = (a.nu == 2 && lane < a.mb) ? a.idf_b[lane] : 1;
-    float pv0 = a.Pv[(size_t)0 * a.ldp + rowc], pv1 = a.Pv[(size_t)1 * a.ldp + rowc], pv2 = a.Pv[(size_t)2 * a.ldp + rowc];
-    float x   = a.X[rowc];
-    stamp();
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the DMA pieces have landed
-    if (lane < kLaMaxObs)
-    {
-        s_fx[0][lane] = 3 + 2 * clamp_idf(id_a, a.n) - 2;
-        s_fx[1][lane] = 3 + 2 * clamp_idf(id_b, a.n) - 2;
-    }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the DMA pieces (and the column loads above) have landed
     __syncthreads();
     stamp();
-    // ---- round 2: the landmark columns of this lane's 16 observations, both updates
-    float pcol[2][32];
-    int   fxv[2][16];
+    // exchange area (16 registers x 64 lanes per tile): in G_b's space until G_b is staged, then in G_a's
+    float* xch = s_G[1];
+    float  own[16];  // this wave's tile of the row vector in hand (PHT or W1), accumulator layout
+    float  full[32]; // both tiles
+    auto share = [&]() { // own -> LDS, then both tiles back
 #pragma unroll
-    for (int ub = 0; ub < 2; ub++) // (all the LDS reads first, then every global load back to back)
-    {
-#pragma unroll
-        for (int i = 0; i < 16; i++)
+        for (int r = 0; r < 16; r++)
         {
-            const int o = la_q_of(i >> 3, 2 * (i & 7), lh) >> 1;
-            fxv[ub][i]  = s_fx[ub][o < kLaMaxObs ? o : 0];
+            xch[(wv * 16 + r) * 64 + lane] = own[r];
         }
-    }
+        __syncthreads();
 #pragma unroll
-    for (int ub = 0; ub < 2; ub++)
-    {
-        const int k = ub == 0 ? ka : kb;
-#pragma unroll
-        for (int i = 0; i < 16; i++)
+        for (int t = 0; t < 2; t++)
         {
-            const int  q  = la_q_of(i >> 3, 2 * (i & 7), lh);
-            const bool in = q < k && (ub == 0 || a.nu == 2);
-            const int  fx = in ? fxv[ub][i] : 3;
-            // (unconditional loads, the VALUE is selected: a branch per load would serialise them)
-            const float va = p_sym<float>(a.P, a.ldp, rowc, fx, a.lower);
-            const float vb = p_sym<float>(a.P, a.ldp, rowc, fx + 1, a.lower);
-            pcol[ub][2 * i]     = in ? va : 0.f;
-            pcol[ub][2 * i + 1] = in ? vb : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                full[t * 16 + r] = xch[(t * 16 + r) * 64 + lane];
+            }
         }
-    }
-
-    f32x16 w1[2]; // W1 of the update in hand, accumulator layout (two column tiles)
-    float  pht[32];
-    float  xs = 0.f, xm0 = 0.f, xm1 = 0.f, xm2 = 0.f;
-
-    // PHT[row, :] of update `ub` (0 = a, 1 = b) in the accumulator layout; rows >= n give zeros, pose rows come from sub
-    auto build_pht = [&](auto UB, int k, const float* sub) {
+    };
+    // this wave's tile of PHT[row, :] of update ub (0 = a, 1 = b); rows >= n give zeros, pose rows come from sub
+    auto build_own = [&](auto UB, int k, const float* sub) {
         constexpr int ub = decltype(UB)::value;
 #pragma unroll
-        for (int i = 0; i < 16; i++)
+        for (int i = 0; i < 8; i++)
         {
-            const int   t = i >> 3, r = 2 * (i & 7);
-            const int   q = la_q_of(t, r, lh);
-            const int   o = (q >> 1) < kLaMaxObs ? (q >> 1) : 0;
+            const int    r = 2 * i;
+            const int    q = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int    o = (q >> 1) < kLaMaxObs ? (q >> 1) : 0;
             const float* c = &s_model[ub][14 + o * 10];
-            float v0, v1;
+            float        v0, v1;
             la_pht_pair<float>(c, pv0, pv1, pv2, pcol[ub][2 * i], pcol[ub][2 * i + 1], &v0, &v1);
             const bool in = (q < k) && (row < a.n);
             if (row < 3 && in)
@@ -973,67 +998,88 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
                 v0 = sub[row * k + q];
                 v1 = sub[row * k + q + 1];
             }
-            pht[t * 16 + r]     = in ? v0 : 0.f;
-            pht[t * 16 + r + 1] = in ? v1 : 0.f;
+            own[r]     = in ? v0 : 0.f;
+            own[r + 1] = in ? v1 : 0.f;
         }
     };
-    // W1 = PHT * G on the matrix cores, and the row sums X += PHT u, Pv -= PHT M^T
-    auto gain = [&](auto UB, int k) {
+    // this wave's column tile of W1 = PHT * G on the matrix cores, and its share of the row sums:
+    // wave 0: X += PHT u and Pv[:, 0] -= PHT M_0;  wave 1: Pv[:, 1], Pv[:, 2]
+    f32x16 w1;
+    auto   gain = [&](auto UB, int k) {
         constexpr int ub = decltype(UB)::value;
         const float*  Gs = s_G[ub];
-        w1[0] = f32x16{0};
-        w1[1] = f32x16{0};
-        xs = xm0 = xm1 = xm2 = 0.f;
+        const float*  v0 = wv == 0 ? s_u[ub] : s_M[ub] + k;
+        const float*  v1 = wv == 0 ? s_M[ub] : s_M[ub] + 2 * k;
+        f32x16        ac0 = f32x16{0}, ac1 = f32x16{0}; // two chains (even / odd steps), added at the end
+        float         sa = 0.f, sb = 0.f;
+        const int     cg   = 32 * wv + lj;
+        const bool    cin  = cg < k;
+        const int     cgc  = cin ? cg : 0;
+        // operands first (clamped addresses, unconditional LDS reads, the VALUE is selected: a guarded read compiles to a
+        // branch per read and serialises the whole loop), then the matrix-core steps
+        float g[32], e0[32], e1[32];
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int i = 0; i < 32; i++)
         {
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int   q  = la_q_of(t, r, lh);
-                const int   qc = q < k ? q : 0;
-                const float g0 = (q < k && lj < k) ? Gs[qc * k + lj] : 0.f;
-                const float g1 = (q < k && 32 + lj < k) ? Gs[qc * k + 32 + lj] : 0.f;
-                const float b  = pht[t * 16 + r];
-                w1[0]          = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, b, w1[0], 0, 0, 0);
-                w1[1]          = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, b, w1[1], 0, 0, 0);
-                xs += b * s_u[ub][qc];
-                xm0 += b * s_M[ub][qc];
-                xm1 += b * s_M[ub][k + qc];
-                xm2 += b * s_M[ub][2 * k + qc];
-            }
+            const int q  = la_q_of(i >> 4, i & 15, lh);
+            const int qc = q < k ? q : 0;
+            const float gv = Gs[qc * k + cgc];
+            g[i]  = (q < k && cin) ? gv : 0.f;
+            e0[i] = v0[qc];
+            e1[i] = v1[qc];
         }
-        xs += __shfl_xor(xs, 32);
-        xm0 += __shfl_xor(xm0, 32);
-        xm1 += __shfl_xor(xm1, 32);
-        xm2 += __shfl_xor(xm2, 32);
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+        {
+            const float b = full[i]; // (zero beyond k: the clamped operands above meet a zero)
+            if (i & 1)
+            {
+                ac1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g[i], b, ac1, 0, 0, 0);
+            }
+            else
+            {
+                ac0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g[i], b, ac0, 0, 0, 0);
+            }
+            sa += b * e0[i];
+            sb += b * e1[i];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            w1[r] = ac0[r] + ac1[r];
+        }
+        sa += __shfl_xor(sa, 32);
+        sb += __shfl_xor(sb, 32);
+        if (lh == 0)
+        {
+            s_sum[2 * wv][lj]     = sa;
+            s_sum[2 * wv + 1][lj] = sb;
+        }
     };
     auto store_w1 = [&](float* W, int k, bool last) {
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int r = 0; r < 16; r++)
         {
-#pragma unroll
-            for (int r = 0; r < 16; r++)
+            const int c = la_q_of(wv, r, lh);
+            if (c < k)
             {
-                const int c = la_q_of(t, r, lh);
-                if (c < k)
+                if (row < 3) // pose rows of the panel: kept aside, stored as zero (the stripe carries them)
                 {
-                    if (row < 3) // pose rows of the panel: kept aside, stored as zero (the stripe carries them)
+                    if (last)
                     {
-                        if (last)
-                        {
-                            a.wv_out[(size_t)row * k + c] = w1[t][r];
-                        }
-                        W[(size_t)c * a.ldw + row] = 0.f;
+                        a.wv_out[(size_t)row * k + c] = w1[r];
                     }
-                    else
-                    {
-                        W[(size_t)c * a.ldw + row] = w1[t][r];
-                    }
+                    W[(size_t)c * a.ldw + row] = 0.f;
+                }
+                else
+                {
+                    W[(size_t)c * a.ldw + row] = w1[r];
                 }
             }
         }
     };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
 
     // ================= update a =================
     if (a.valid_a && row >= 3 && row - 3 < a.w_a)
@@ -1042,23 +1088,30 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
         predict_stripe_col<float>(s_model[0][0], s_model[0][1], pv0, pv1, pv2, &o0, &o1, &o2);
         pv0 = o0, pv1 = o1, pv2 = o2;
     }
-    using U0 = std::integral_constant<int, 0>;
-    using U1 = std::integral_constant<int, 1>;
-    build_pht(U0{}, ka, a.sub_a);
+    build_own(U0{}, ka, a.sub_a);
+    share();
     stamp();
     gain(U0{}, ka);
     stamp();
     store_w1(a.W1a, ka, a.nu == 1);
-    stamp();
     const float* pred_last = s_model[0];
     if (a.nu == 2)
     {
-        // state of the rows after update a (pose rows: the chain's values are taken at the end)
-        if (row >= 3)
+        // W1_a[row, :] for the correction: both tiles through the exchange area (after everybody has read PHT_a from it)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            own[r] = (row >= 3) ? w1[r] : 0.f; // (the panel's pose rows are zero)
+        }
+        share(); // (its barrier also publishes the row sums of update a)
+        const float xs = s_sum[0][lj], xm0 = s_sum[1][lj], xm1 = s_sum[2][lj], xm2 = s_sum[3][lj];
+        if (row >= 3) // state of the rows after update a (pose rows: the chain's values are taken at the end)
         {
             x += xs;
             pv0 -= xm0, pv1 -= xm1, pv2 -= xm2;
         }
+        stamp();
         // ================= update b =================
         if (a.valid_b && row >= 3 && row - 3 < a.w_b)
         {
@@ -1066,48 +1119,63 @@ __global__ void __launch_bounds__(64) ekf_la_wide_f32(LaWideArgs a)
             predict_stripe_col<float>(s_model[1][0], s_model[1][1], pv0, pv1, pv2, &o0, &o1, &o2);
             pv0 = o0, pv1 = o1, pv2 = o2;
         }
-        const f32x16 wa0 = w1[0], wa1 = w1[1]; // W1_a[row, :], accumulator layout = the operand layout of the correction
-        build_pht(U1{}, kb, a.sub_b);
-        stamp();
-        // PHT_b -= W1_a * Y_b^T : D[i = q][j = row] += Y_b[c][q] * W1_a[row][c] over c
-        f32x16 cr[2] = {f32x16{0}, f32x16{0}};
-#pragma unroll
-        for (int t = 0; t < 2; t++)
+        build_own(U1{}, kb, a.sub_b);
+        // this wave's tile of PHT_b -= W1_a * Y_b^T : D[i = q][j = row] += Y_b[c][q] * W1_a[row][c] over c (both tiles)
         {
+            f32x16     c0 = f32x16{0}, c1 = f32x16{0};
+            const int  qg  = 32 * wv + lj;
+            const bool qin = qg < kb;
+            const int  qgc = qin ? qg : 0;
+            float      y[32];
 #pragma unroll
-            for (int r = 0; r < 16; r++)
+            for (int i = 0; i < 32; i++)
             {
-                const int   c  = la_q_of(t, r, lh);
+                const int   c  = la_q_of(i >> 4, i & 15, lh);
                 const int   cc = c < ka ? c : 0;
-                const float y0 = (c < ka && lj < kb) ? s_Y[cc * kb + lj] : 0.f;
-                const float y1 = (c < ka && 32 + lj < kb) ? s_Y[cc * kb + 32 + lj] : 0.f;
-                const float b  = (row >= 3) ? (t == 0 ? wa0[r] : wa1[r]) : 0.f; // (the panel's pose rows are zero)
-                cr[0]          = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, b, cr[0], 0, 0, 0);
-                cr[1]          = __builtin_amdgcn_mfma_f32_32x32x2f32(y1, b, cr[1], 0, 0, 0);
+                const float yv = s_Y[cc * kb + qgc];
+                y[i]           = (c < ka && qin) ? yv : 0.f;
             }
-        }
-        if (row >= 3)
-        {
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+            for (int i = 0; i < 32; i++)
+            {
+                if (i & 1)
+                {
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y[i], full[i], c1, 0, 0, 0);
+                }
+                else
+                {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(y[i], full[i], c0, 0, 0, 0);
+                }
+            }
+            if (row >= 3)
             {
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                 {
-                    pht[t * 16 + r] -= cr[t][r];
+                    own[r] -= c0[r] + c1[r];
                 }
             }
         }
         stamp();
+        // the exchange area moves into G_a's space (dead since gain a); G_b is staged into its own
+        __syncthreads(); // (everybody is done with W1_a in the old exchange area)
+        dma(a.Gt_b, kb * kb, s_G[1]);
+        xch = s_G[0];
+        share();
+        __builtin_amdgcn_s_waitcnt(0x0F70); // G_b has landed ...
+        __syncthreads();                    // ... for both waves; the row sums of update a have been read by everybody
+        stamp();
         gain(U1{}, kb);
         stamp();
         store_w1(a.W1b, kb, true);
-        stamp();
         pred_last = s_model[1];
     }
-    // ================= commit X and the stripe (the last update's sums are in xs / xm) =================
-    if (lh == 0 && row < a.n)
+    __syncthreads(); // the row sums of the last update
+    stamp();
+    // ================= commit X and the stripe =================
+    if (wv == 0 && lh == 0 && row < a.n)
     {
+        const float xs = s_sum[0][lj], xm0 = s_sum[1][lj], xm1 = s_sum[2][lj], xm2 = s_sum[3][lj];
         if (row >= 3)
         {
             a.X[row]                        = x + xs;
