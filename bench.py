@@ -74,7 +74,7 @@ def parse_args():
                          "default: 128 for batches of 32 observations -- one P-GEMM per two updates --, else 0)")
     ap.add_argument("--instances", type=int, default=8, help="mc: filter instances per GPU")
     ap.add_argument("--pgemm-wgs", type=int, default=-1,
-                    help="mc: cap on each instance's persistent P-GEMM grid (-1: 512 / instances, 0: whole chip)")
+                    help="mc: cap on each instance's persistent P-GEMM grid (-1 / 0: whole chip)")
     ap.add_argument("--particles", type=int, default=512)
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--pf-obs", type=int, default=8)
@@ -710,7 +710,9 @@ def mc_main(args):
         w = Workload(N, m, dtype, seed=100 + rank * I + i)
         e = EKF(N, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
         e.set_state(w.X0, w.P0)
-        e.set_pgemm_workgroups(max(32, 512 // I) if args.pgemm_wgs < 0 else args.pgemm_wgs)
+        # (whole-chip P-GEMM grids per instance: capping them at 512 / I was measured slower -- 25.9 k vs 35 - 38 k
+        # aggregate steps/s, DESIGN.md 6 -- so the cap is opt-in)
+        e.set_pgemm_workgroups(0 if args.pgemm_wgs < 0 else args.pgemm_wgs)
         if args.defer < 0:
             # as the headline: one k = 128 P-GEMM per two updates -- 3.5 launches per step instead of 4, and the runs are
             # launch-bound (measured on one GPU: 34.8 k / 38.4 k / 33.3 k aggregate steps/s with windows of 0 / 128 / 256)

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -36,6 +37,15 @@ using namespace cslam;
 
 namespace
 {
+
+// Live engines of this process.  The look-ahead windows' fast hand-overs are waits INSIDE kernels (the chain kernel is
+// launched early and waits for the blocks kernel; the wide kernel polls the chain's completion word).  They are only safe
+// while the two streams of ONE engine have the device to themselves: with several engines, streams share the few hardware
+// queues (a chain kernel spinning at the head of a queue blocks the kernel it waits for when that one sits behind another
+// engine's waiting kernel in a second queue) and spinning wide kernels can hold every compute unit -- measured as 0.2 s
+// time-outs with 8 co-running instances.  So with more than one engine alive: windows only if forced
+// (CSLAM_LOOKAHEAD=1), and then with stream events only (ev_raw / ev_fb): a plain dependency graph, no waiting kernels.
+std::atomic<int> g_engines{0};
 
 constexpr int    kStagingSlots = 64;
 constexpr size_t kLdsBudget    = 150 * 1024; // of the 160 KiB per CU, leave room for the small arrays
@@ -186,6 +196,7 @@ struct Ekf : EkfBase
         {
             (void)hipStreamSynchronize(stream_f);
             (void)hipEventDestroy(ev_fb);
+            (void)hipEventDestroy(ev_raw);
             (void)hipStreamDestroy(stream_f);
         }
         la_free();
@@ -1487,7 +1498,8 @@ struct Ekf : EkfBase
     int         la_n = 0;
     FactorOut   fo[2];
     hipStream_t stream_f = nullptr;
-    hipEvent_t  ev_fb = nullptr; // the chain kernel of the last window has finished
+    hipEvent_t  ev_fb = nullptr;  // the chain kernel of the last window has finished
+    hipEvent_t  ev_raw = nullptr; // the blocks kernel of the last window has finished (several engines alive only)
     T *         la_XL = nullptr, *la_PvL = nullptr, *la_WR = nullptr, *la_PH = nullptr, *la_PvLb = nullptr, *la_Dbb = nullptr;
     T*          la_Y = nullptr;         // H_b * W1_a of the last window (for a fused wide kernel)
     LaModel<T>* la_model = nullptr;     // [2]: predict + observation model of update a / b
@@ -1565,6 +1577,7 @@ struct Ekf : EkfBase
             CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream_f, hipStreamNonBlocking, hi));
             la_cus = 1;
             CSLAM_HIP_TRY(hipEventCreateWithFlags(&ev_fb, hipEventDisableTiming));
+            CSLAM_HIP_TRY(hipEventCreateWithFlags(&ev_raw, hipEventDisableTiming));
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_la_chain_kernel<T, 32>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)la_chain_lds(32)));
             CSLAM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_la_chain_kernel<T, 64>),
@@ -1626,7 +1639,7 @@ struct Ekf : EkfBase
         // lookahead: 1 on, 0 off, -1 (default) where it pays: f32 and a P-GEMM long enough to hide the factor chain
         // (~70 us) underneath it -- about N >= 3500 landmarks; a short P-GEMM leaves the chain on the critical path
         // (measured: f64 N = 1000 12.9 k steps/s with windows against 15.8 k without)
-        const bool on = lookahead > 0 || (lookahead < 0 && sizeof(T) == 4 && n >= 7000);
+        const bool on = lookahead > 0 || (lookahead < 0 && sizeof(T) == 4 && n >= 7000 && g_engines.load() == 1);
         return on && !sync_mode && !pipeline && profiling != 1 && k > 16 && k <= 2 * kLaMaxObs && gather_corr_wide &&
                fuse_predict && (sizeof(T) == 4 || fuse_f64) && defer_max >= k + (la_n ? 2 * la_q[0].m : k) &&
                wcap >= k + (la_n ? 2 * la_q[0].m : k) && seq.count == 0 && hd_cols[0] == 0 && hd_cols[1] == 0 && n > 3 &&
@@ -1762,9 +1775,11 @@ struct Ekf : EkfBase
             return rc;
         }
         // 1. the factor chain of the window on stream F, ONE launch, submitted first: it takes a compute unit for itself
-        //    and waits there (on a counter) for the blocks kernel below
+        //    and waits there (on a counter) for the blocks kernel below.  (safe: several engines alive -- the chain kernel is
+        //    launched behind the blocks kernel's event instead, see g_engines)
+        const bool     safe     = g_engines.load() > 1;
         const unsigned n_blocks = (unsigned)(3 + ka + 2 * kb);
-        {
+        auto launch_chain = [&]() -> int {
             LaChainArgs<T> ch;
             ch.fa   = la_factor_args(ua, fo[0]);
             ch.fb   = la_factor_args(nu == 2 ? ub : ua, fo[1]);
@@ -1805,6 +1820,11 @@ struct Ekf : EkfBase
             }
             CSLAM_HIP_TRY(hipGetLastError());
             CSLAM_HIP_TRY(hipEventRecord(ev_fb, stream_f));
+            return CSLAM_OK;
+        };
+        if (!safe && (rc = launch_chain()))
+        {
+            return rc;
         }
         // 2. what the chain needs of the current covariance P = Ps - Wp Wp^T (before Ps changes): rows of the pending
         //    panels, then one workgroup per row of the small blocks; update a's compact block sub_a comes out of it ready
@@ -1839,6 +1859,15 @@ struct Ekf : EkfBase
         pa.done    = la_done;
         hipLaunchKernelGGL(ekf_la_blocks_kernel<T>, dim3(n_blocks), dim3(64), 0, stream, pa);
         CSLAM_HIP_TRY(hipGetLastError());
+        if (safe)
+        {
+            CSLAM_HIP_TRY(hipEventRecord(ev_raw, stream));
+            CSLAM_HIP_TRY(hipStreamWaitEvent(stream_f, ev_raw, 0));
+            if ((rc = launch_chain())) // (its wait for the blocks kernel's counters passes at once)
+            {
+                return rc;
+            }
+        }
         la_target += n_blocks;
         // 3. the P-GEMM of everything pending (the previous window's panels): stream F works underneath it
         if ((rc = flush()))
@@ -1853,6 +1882,10 @@ struct Ekf : EkfBase
             if (la_fused)
             {
                 fused = true;
+                if (safe) // (see g_engines: no waiting inside the wide kernel then)
+                {
+                    CSLAM_HIP_TRY(hipStreamWaitEvent(stream, ev_fb, 0));
+                }
                 LaWideArgs wa;
                 wa.chain_done = la_done + 256; // (waits for the chain kernel in the kernel: a stream event costs ~6 us here)
                 wa.seq        = la_seq;
@@ -2562,6 +2595,7 @@ int cslam_ekf_create(int max_landmarks, int dtype, int device, int quirks, cslam
         delete b;
         return rc;
     }
+    g_engines.fetch_add(1);
     *out = reinterpret_cast<cslam_ekf_t>(b);
     return CSLAM_OK;
 }
@@ -2574,6 +2608,7 @@ int cslam_ekf_destroy(cslam_ekf_t h)
     }
     (void)hipSetDevice(B(h)->device);
     delete B(h);
+    g_engines.fetch_sub(1);
     return CSLAM_OK;
 }
 
