@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per_call / dropin / reference_loop sub-records")
     ap.add_argument("--stage-profile", action="store_true", help="extra untimed pass with events around every stage")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="ekf: CSLAM_LOOKAHEAD=0 -- every update runs its own gather / factor / gain chain (round 2's engine)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses device 0 and the ranks rendezvous "
                          "over gloo (RCCL refuses one device twice); exercises the launcher / rank logic, not xGMI")
@@ -389,7 +391,8 @@ def ekf_main(args):
         preheat_steps -= n_cold
     for t in range(pre_cap, pre_cap + args.warmup):
         step(t)
-    barrier()
+    eng.flush()  # (the timed region starts from an applied state: the warm-up's pending P-GEMM is not billed to it,
+    barrier()    #  and the K timed steps pay for all of their own, the final flush included)
     # HIP events around a sample of the P-GEMM launches of the timed region, on the stream they run on (an event pair
     # costs ~11 us of stream time around the kernel it brackets: one launch in 16, or in 4 for short runs)
     eng.set_profiling(3 if args.steps >= 200 else 4)
@@ -968,6 +971,8 @@ def pf_main(args):
 
 def main():
     args = parse_args()
+    if args.no_lookahead:
+        os.environ["CSLAM_LOOKAHEAD"] = "0"
     launch_ranks_if_needed(args)
     if args.workload == "pf":
         return pf_main(args)
