@@ -8,7 +8,7 @@ library or without a GPU raises.
 from . import _capi  # noqa: F401
 from ._capi import (CslamError, F32, F64, Q_LOWER_CHOL_GAIN, Q_PREDICT_NM4, Q_REF_EXACT, Q_TEXTBOOK,  # noqa: F401
                     device_count)
-from .ekf import EKF  # noqa: F401
+from .ekf import EKF, EKFBatch  # noqa: F401
 from .sim import Simulator  # noqa: F401
 
-__all__ = ["EKF", "Simulator", "CslamError", "F32", "F64", "Q_REF_EXACT", "Q_TEXTBOOK", "device_count"]
+__all__ = ["EKF", "EKFBatch", "Simulator", "CslamError", "F32", "F64", "Q_REF_EXACT", "Q_TEXTBOOK", "device_count"]

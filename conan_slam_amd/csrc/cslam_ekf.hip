@@ -33,6 +33,15 @@
 #include "ekf_pose_kernels.hpp"
 #include "host_linalg.hpp"
 
+namespace cslam
+{
+// the wide half of a look-ahead window (ekf_lookahead.hpp: ekf_la_wide_body), one filter
+__global__ void __launch_bounds__(128) ekf_la_wide_f32(LaWideArgs a)
+{
+    ekf_la_wide_body(a);
+}
+} // namespace cslam
+
 using namespace cslam;
 
 namespace
@@ -1830,8 +1839,24 @@ struct Ekf : EkfBase
         //    panels, then one workgroup per row of the small blocks; update a's compact block sub_a comes out of it ready
         //    for the factor step.  (From here to the blocks launch nothing may fail: the chain kernel is waiting.)
         const T* Wp = wbase(wcur);
-        hipLaunchKernelGGL(ekf_la_rows_kernel<T>, dim3(ka + kb), dim3(128), 0, stream, dX, dPv, ldp, n, ua.dIdf, ka,
-                           nu == 2 ? ub.dIdf : ua.dIdf, kb, Wp, ldp, kp, la_kpad, la_XL, la_PvL, la_WR, dFlags);
+        LaRowsArgs<T> ra;
+        ra.X     = dX;
+        ra.Pv    = dPv;
+        ra.ldp   = ldp;
+        ra.n     = n;
+        ra.idf_a = ua.dIdf;
+        ra.ra    = ka;
+        ra.idf_b = nu == 2 ? ub.dIdf : ua.dIdf;
+        ra.rb    = kb;
+        ra.Wp    = Wp;
+        ra.ldw   = ldp;
+        ra.kp    = kp;
+        ra.kpad  = la_kpad;
+        ra.XL    = la_XL;
+        ra.PvL   = la_PvL;
+        ra.WR    = la_WR;
+        ra.flags = dFlags;
+        hipLaunchKernelGGL(ekf_la_rows_kernel<T>, dim3(ka + kb), dim3(128), 0, stream, ra);
         LaPrepArgs<T> pa;
         pa.P       = dP;
         pa.ldp     = ldp;

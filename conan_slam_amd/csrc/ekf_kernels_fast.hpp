@@ -2305,12 +2305,17 @@ ekf_downdate_psym_f32(float* __restrict__ P, int ldp, const float* __restrict__ 
 // PF: the LDS operands of k-pair g+1 are requested BEFORE the four MFMAs of k-pair g are issued (software pipelining:
 // the scheduling barriers between k-pairs otherwise put every group's LDS latency in front of its MFMAs).  It matters
 // where the launch is matrix-bound (k = 128: 4 chunks).
-template <int NTMODE, int NCH, int KC = 32, bool PF = false>
+// BATCH (cslam_ekf_batch.hip): P and W1 are slabs of independent filters of the same size, instance i at byte offsets
+// i * sP / i * sW; a tile's x carries the instance in its upper 16 bits, p_span / w_span are the slabs' sizes in bytes
+// (< 4 GiB), and every instance's panel must be zero beyond its pending columns up to NCH * KC (the host clears them:
+// the resource bound that delivers those zeros for one filter spans the whole slab here).
+template <int NTMODE, int NCH, int KC = 32, bool PF = false, bool BATCH = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__ W1, int ldw, int k8,
                        const int2* __restrict__ tile_list_in, int ntiles_in, int* __restrict__ ticket_in,
                        int* __restrict__ ticket_reset, unsigned long long* __restrict__ hwids,
-                       const int* __restrict__ seg_off = nullptr)
+                       const int* __restrict__ seg_off = nullptr, unsigned sP = 0, unsigned sW = 0, unsigned p_span = 0,
+                       unsigned w_span = 0)
 {
     // seg_off != nullptr: one tile queue per XCD.  tile_list_in is then Morton-ordered and cut into eight segments
     // (seg_off[0..8]), ticket_in / ticket_reset are eight counters each, and workgroup b works on queue b & 7 -- its
@@ -2344,11 +2349,18 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
     constexpr int kAuxLd = (NTMODE == 1 || NTMODE == 2) ? 2 : ((NTMODE >= 4) ? 16 : 0); // bit 1: nt, bit 4: sc1
     constexpr int kAuxSt = (NTMODE == 1 || NTMODE == 3 || NTMODE == 6) ? 2 : ((NTMODE == 5) ? 16 : 0);
     // (P must be < 4 GiB: ldp < 32768; the host checks.)
-    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P, 0, (unsigned)((size_t)ldp * ldp * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W1), 0, (unsigned)((size_t)k8 * ldw * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsP =
+        __builtin_amdgcn_make_buffer_rsrc(P, 0, BATCH ? p_span : (unsigned)((size_t)ldp * ldp * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(W1), 0, BATCH ? w_span : (unsigned)((size_t)k8 * ldw * 4), 0x00020000);
     const unsigned lane_off = (unsigned)(((wave * 32 + 4 * lh) * ldp + 4 * lj) * 4);
-    auto tile_base = [&](int2 t) -> unsigned { return (unsigned)(((size_t)(t.y * 128) * ldp + t.x * 128) * 4); };
+    auto tile_base = [&](int2 t) -> unsigned {
+        if constexpr (BATCH)
+        {
+            return (unsigned)(t.x >> 16) * sP + (unsigned)(((size_t)(t.y * 128) * ldp + (t.x & 0xFFFF) * 128) * 4);
+        }
+        return (unsigned)(((size_t)(t.y * 128) * ldp + t.x * 128) * 4);
+    };
     auto row_off   = [&](int r) -> unsigned { return (unsigned)(((r & 3) + 8 * (r >> 2)) * ldp * 4); };
     auto load1     = [&](unsigned tbase, int r) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, lane_off, tbase + row_off(r), kAuxLd));
@@ -2361,7 +2373,9 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
     const unsigned dma_lane_off = (unsigned)((lh * ldw + 4 * lj) * 4);
     auto dma_chunk = [&](int2 t, auto C) { // C: chunk index (compile time); LDS buffer pair C & 1
         constexpr int  c    = decltype(C)::value;
-        const unsigned row0 = (unsigned)(t.x * 128 * 4), col0 = (unsigned)(t.y * 128 * 4);
+        const unsigned ibase = BATCH ? (unsigned)(t.x >> 16) * sW : 0u;
+        const unsigned row0  = ibase + (unsigned)((BATCH ? (t.x & 0xFFFF) : t.x) * 128 * 4);
+        const unsigned col0  = ibase + (unsigned)(t.y * 128 * 4);
 #pragma unroll
         for (int it = 0; it < KC / 8; it++)
         {

@@ -50,13 +50,35 @@ __device__ inline int la_row(const int* __restrict__ idf, int s, int n)
 // grid = ra + rb workgroups of 128 threads.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(128) ekf_la_rows_kernel(const T* __restrict__ X, const T* __restrict__ Pv, int ldp, int n,
-                                                           const int* __restrict__ idf_a, int ra,
-                                                           const int* __restrict__ idf_b, int rb,
-                                                           const T* __restrict__ Wp, int ldw, int kp, int kpad,
-                                                           T* __restrict__ XL, T* __restrict__ PvL, T* __restrict__ WR,
-                                                           int* __restrict__ flags)
+struct LaRowsArgs
 {
+    const T* X;
+    const T* Pv;
+    int      ldp, n;
+    const int* idf_a;
+    int        ra;
+    const int* idf_b;
+    int        rb;
+    const T*   Wp;
+    int        ldw, kp, kpad;
+    T *        XL, *PvL, *WR;
+    int*       flags;
+};
+
+template <typename T>
+__device__ __forceinline__ void ekf_la_rows_body(const LaRowsArgs<T>& a)
+{
+    const T* __restrict__ X = a.X;
+    const T* __restrict__ Pv = a.Pv;
+    const int ldp = a.ldp, n = a.n, ra = a.ra, rb = a.rb, ldw = a.ldw, kp = a.kp;
+    const int* __restrict__ idf_a = a.idf_a;
+    const int* __restrict__ idf_b = a.idf_b;
+    const T* __restrict__ Wp = a.Wp;
+    T* __restrict__ XL = a.XL;
+    T* __restrict__ PvL = a.PvL;
+    T* __restrict__ WR = a.WR;
+    int* __restrict__ flags = a.flags;
+
     const int s   = blockIdx.x;
     if (threadIdx.x == 4) // (device-resident feature ids cannot be checked by the host: clamped everywhere, flagged here)
     {
@@ -79,6 +101,12 @@ __global__ void __launch_bounds__(128) ekf_la_rows_kernel(const T* __restrict__ 
     {
         XL[s] = X[row];
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(128) ekf_la_rows_kernel(LaRowsArgs<T> a)
+{
+    ekf_la_rows_body<T>(a);
 }
 
 
@@ -180,7 +208,7 @@ struct LaPrepArgs
 // the stripe).  (s, s') and (s', s) read the same element of Ps and add the same products in the same order.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(64) ekf_la_blocks_kernel(LaPrepArgs<T> a)
+__device__ __forceinline__ void ekf_la_blocks_body(const LaPrepArgs<T>& a)
 {
     __shared__ T wrow[256];
     __shared__ T s_xl[3 + 2 * kLaMaxObs];
@@ -365,6 +393,12 @@ __global__ void __launch_bounds__(64) ekf_la_blocks_kernel(LaPrepArgs<T> a)
     {
         atomicAdd(a.done + 16 * (blockIdx.x & 15u), 1u); // (16 counters, 64 bytes apart: ~200 atomics on ONE word take ~5 us)
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) ekf_la_blocks_kernel(LaPrepArgs<T> a)
+{
+    ekf_la_blocks_body<T>(a);
 }
 
 template <typename T>
@@ -719,7 +753,7 @@ struct LaChainArgs
 };
 
 template <typename T, int K>
-__global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
+__device__ __forceinline__ void ekf_la_chain_body(const LaChainArgs<T>& a)
 {
     extern __shared__ __align__(16) unsigned char la_chain_smem[];
     if (threadIdx.x < 64) // (wave 0: lanes 0..15 read one counter each)
@@ -787,6 +821,12 @@ __global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
     }
 }
 
+template <typename T, int K>
+__global__ void __launch_bounds__(256) ekf_la_chain_kernel(LaChainArgs<T> a)
+{
+    ekf_la_chain_body<T, K>(a);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The WIDE half of a look-ahead window in ONE launch (f32): with the factors of both updates known, every block of 32
 // rows applies update a and update b to itself -- what ekf_gather_kernel + ekf_panel_mfma_f32 (+ the in-kernel
@@ -833,7 +873,7 @@ __device__ __forceinline__ int la_q_of(int t, int r, int lh)
     return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
 }
 
-__global__ void __launch_bounds__(128) ekf_la_wide_f32(LaWideArgs a)
+__device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
 {
     // TWO waves per block of 32 rows.  Wave w owns column tile w (32 columns) of every product -- half the matrix-core
     // chain, half the operand reads -- and builds tile w of PHT; the halves meet through LDS (one 8 KB exchange area,
@@ -1206,6 +1246,231 @@ __global__ void __launch_bounds__(128) ekf_la_wide_f32(LaWideArgs a)
             }
         }
     }
+}
+
+// (the __global__ wrapper ekf_la_wide_f32 lives in cslam_ekf.hip, the batched one in cslam_ekf_batch.hip: a non-template kernel
+// in a header would be defined once per translation unit)
+
+// ------------------------------------------------------------------------------------------------
+// BATCHED look-ahead windows (cslam_ekf_batch.hip): I independent f32 filters of the same size advance in lockstep -- the
+// Monte-Carlo runs of BASELINE configs[4], test/main.cpp:132-200 x I.  Every stage of a window is ONE launch for all
+// instances (blockIdx.y = instance): rows, blocks, the factor chain (I workgroups on stream F) and the wide half; the
+// P-GEMMs are I launches of the single-filter kernel.  The instances live in slabs with a fixed stride per buffer class,
+// so a kernel derives its instance's arguments from this one struct (passed by value: no per-window copies).
+// ------------------------------------------------------------------------------------------------
+namespace labatch
+{
+// per-instance factor block (floats): two slots (update a / b of the window)
+constexpr int kS = 0, kG = 4160, kGt = 8320, kV = 12480, kT = 12544, kU = 12608, kM = 12672, kSub = 12864, kXloc = 17152;
+constexpr int kSlot = 17280, kFoBlock = 2 * kSlot;
+// per-instance look-ahead block (floats)
+constexpr int kXL = 0, kPvL = 128, kPH = 512, kPvLb = 4608, kDbb = 4864, kY = 8960, kModel = 13056, kWR = 13760;
+constexpr int kModelStride = 336, kKpad = 128, kLaBlock = kWR + kKpad * 128;
+constexpr int kDoneBlock = 768; // unsigned words per instance: 16 counters (stride 16) + 32 chain words (stride 16) at 256
+} // namespace labatch
+
+struct LaBatchWin
+{
+    int I, n, ldp, lower, textbook;
+    float*  X;    // [I][ldp]
+    float*  Pv;   // [I][3 ldp]
+    float*  P;    // [I][ldp ldp]
+    float*  Wp;   // pending region of instance 0 (its kp columns are what the coming P-GEMM applies)
+    float*  Wn;   // the region the window's W1 panels go to (instance 0, column 0)
+    long    sW;   // per-instance stride of the pending store (floats)
+    float*  fo;   // [I][kFoBlock]
+    float*  la;   // [I][kLaBlock]
+    float*  wv;   // [I][3 * 64]
+    unsigned* done; // [I][kDoneBlock]
+    int*      flags; // [I][2]
+    int*      idloc; // [I][kLaMaxObs]: 1 .. m
+    const float* const* Ztab; // user pointers per instance
+    const int* const*   idftab;
+    long zoff_a, zoff_b, ioff_a, ioff_b; // element offsets of update a / b in each instance's arrays
+    int  ma, mb, nu;
+    PredictArgs<float> pp_a, pp_b;
+    float R[4];
+    int   kp;
+    unsigned target, seq;
+    unsigned long long timeout;
+};
+
+__device__ __forceinline__ LaRowsArgs<float> la_batch_rows(const LaBatchWin& w, int i)
+{
+    using namespace labatch;
+    float*            la = w.la + (size_t)i * kLaBlock;
+    LaRowsArgs<float> a;
+    a.X     = w.X + (size_t)i * w.ldp;
+    a.Pv    = w.Pv + (size_t)i * 3 * w.ldp;
+    a.ldp   = w.ldp;
+    a.n     = w.n;
+    a.idf_a = w.idftab[i] + w.ioff_a;
+    a.ra    = 2 * w.ma;
+    a.idf_b = w.idftab[i] + (w.nu == 2 ? w.ioff_b : w.ioff_a);
+    a.rb    = 2 * w.mb;
+    a.Wp    = w.Wp + (size_t)i * w.sW;
+    a.ldw   = w.ldp;
+    a.kp    = w.kp;
+    a.kpad  = kKpad;
+    a.XL    = la + kXL;
+    a.PvL   = la + kPvL;
+    a.WR    = la + kWR;
+    a.flags = w.flags + 2 * i;
+    return a;
+}
+
+__device__ __forceinline__ LaPrepArgs<float> la_batch_prep(const LaBatchWin& w, int i)
+{
+    using namespace labatch;
+    float*            la = w.la + (size_t)i * kLaBlock;
+    float*            fo = w.fo + (size_t)i * kFoBlock;
+    LaPrepArgs<float> a;
+    a.P       = w.P + (size_t)i * w.ldp * w.ldp;
+    a.ldp     = w.ldp;
+    a.n       = w.n;
+    a.lower   = w.lower;
+    a.X       = w.X + (size_t)i * w.ldp;
+    a.Pv      = w.Pv + (size_t)i * 3 * w.ldp;
+    a.idf_a   = w.idftab[i] + w.ioff_a;
+    a.idf_b   = w.idftab[i] + (w.nu == 2 ? w.ioff_b : w.ioff_a);
+    a.ra      = 2 * w.ma;
+    a.rb      = 2 * w.mb;
+    a.pp_a    = w.pp_a;
+    a.XL      = la + kXL;
+    a.PvL     = la + kPvL;
+    a.WR      = la + kWR;
+    a.kp      = w.kp;
+    a.kpad    = kKpad;
+    a.sub_a   = fo + kSub;
+    a.PH      = la + kPH;
+    a.Dbb     = la + kDbb;
+    a.PvLb    = la + kPvLb;
+    a.model_a = reinterpret_cast<LaModel<float>*>(la + kModel);
+    a.xloc_a  = fo + kXloc;
+    a.idloc   = w.idloc + kLaMaxObs * i;
+    a.done    = w.done + (size_t)i * kDoneBlock;
+    return a;
+}
+
+__device__ __forceinline__ FactorArgs<float> la_batch_factor(const LaBatchWin& w, int i, int slot)
+{
+    using namespace labatch;
+    float*            fo = w.fo + (size_t)i * kFoBlock + (size_t)slot * kSlot;
+    FactorArgs<float> a;
+    a.X   = fo + kXloc;
+    a.n   = 3 + 2 * (slot == 0 ? w.ma : w.mb);
+    a.Z   = w.Ztab[i] + (slot == 0 ? w.zoff_a : w.zoff_b);
+    a.idf = w.idloc + kLaMaxObs * i;
+    a.m   = slot == 0 ? w.ma : w.mb;
+    for (int e = 0; e < 4; e++)
+    {
+        a.R[e] = w.R[e];
+    }
+    a.PHT      = nullptr;
+    a.ldw      = w.ldp;
+    a.dS       = fo + kS;
+    a.dG       = fo + kG;
+    a.dGt      = fo + kGt;
+    a.dV       = fo + kV;
+    a.dt       = fo + kT;
+    a.flags    = w.flags + 2 * i;
+    a.scratchS = nullptr;
+    a.scratchG = nullptr;
+    a.stamps   = nullptr;
+    a.sub      = fo + kSub;
+    a.dM       = fo + kM;
+    a.pp       = PredictArgs<float>{0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+    a.P3       = w.Pv + (size_t)i * 3 * w.ldp;
+    a.ldp3     = w.ldp;
+    a.pred_out = nullptr;
+    a.lds_S    = 1;
+    a.lds_G    = 1;
+    a.textbook = w.textbook;
+    return a;
+}
+
+__device__ __forceinline__ LaChainArgs<float> la_batch_chain(const LaBatchWin& w, int i)
+{
+    using namespace labatch;
+    float*             la = w.la + (size_t)i * kLaBlock;
+    float*             f0 = w.fo + (size_t)i * kFoBlock;
+    float*             f1 = f0 + kSlot;
+    LaChainArgs<float> c;
+    c.fa   = la_batch_factor(w, i, 0);
+    c.fb   = la_batch_factor(w, i, w.nu == 2 ? 1 : 0);
+    c.du_a = f0 + kU;
+    c.du_b = f1 + kU;
+    c.nu   = w.nu;
+    c.done = w.done + (size_t)i * kDoneBlock;
+    c.target     = w.target;
+    c.timeout    = w.timeout;
+    c.chain_done = w.done + (size_t)i * kDoneBlock + 256;
+    c.seq        = w.seq;
+    LaCarryArgs<float>& ca = c.ca;
+    ca.n       = w.n;
+    ca.m_a     = w.ma;
+    ca.m_b     = w.nu == 2 ? w.mb : 0;
+    ca.idf_b   = w.idftab[i] + (w.nu == 2 ? w.ioff_b : w.ioff_a);
+    ca.pp_b    = w.nu == 2 ? w.pp_b : w.pp_a;
+    ca.PH      = la + kPH;
+    ca.Dbb     = la + kDbb;
+    ca.PvLb    = la + kPvLb;
+    ca.XLb     = la + kXL + 2 * w.ma;
+    ca.model_a = reinterpret_cast<const LaModel<float>*>(la + kModel);
+    ca.Gt_a    = f0 + kGt;
+    ca.u_a     = f0 + kU;
+    ca.M_a     = f0 + kM;
+    ca.sub_a   = f0 + kSub;
+    ca.sub_b   = f1 + kSub;
+    ca.xloc_b  = f1 + kXloc;
+    ca.model_b = reinterpret_cast<LaModel<float>*>(la + kModel + kModelStride);
+    ca.Y_b     = la + kY;
+    return c;
+}
+
+__device__ __forceinline__ LaWideArgs la_batch_wide(const LaBatchWin& w, int i)
+{
+    using namespace labatch;
+    float*     la = w.la + (size_t)i * kLaBlock;
+    float*     f0 = w.fo + (size_t)i * kFoBlock;
+    float*     f1 = f0 + kSlot;
+    LaWideArgs a;
+    a.P       = w.P + (size_t)i * w.ldp * w.ldp;
+    a.ldp     = w.ldp;
+    a.n       = w.n;
+    a.lower   = w.lower;
+    a.X       = w.X + (size_t)i * w.ldp;
+    a.Pv      = w.Pv + (size_t)i * 3 * w.ldp;
+    a.nu      = w.nu;
+    a.idf_a   = w.idftab[i] + w.ioff_a;
+    a.idf_b   = w.idftab[i] + (w.nu == 2 ? w.ioff_b : w.ioff_a);
+    a.ma      = w.ma;
+    a.mb      = w.nu == 2 ? w.mb : 0;
+    a.valid_a = w.pp_a.valid;
+    a.valid_b = w.nu == 2 ? w.pp_b.valid : 0;
+    a.w_a     = w.pp_a.w;
+    a.w_b     = w.nu == 2 ? w.pp_b.w : 0;
+    a.model_a = reinterpret_cast<const LaModel<float>*>(la + kModel);
+    a.model_b = reinterpret_cast<const LaModel<float>*>(la + kModel + kModelStride);
+    a.Gt_a    = f0 + kGt;
+    a.u_a     = f0 + kU;
+    a.M_a     = f0 + kM;
+    a.sub_a   = f0 + kSub;
+    a.Gt_b    = f1 + kGt;
+    a.u_b     = f1 + kU;
+    a.M_b     = f1 + kM;
+    a.sub_b   = f1 + kSub;
+    a.Y_b     = la + kY;
+    a.W1a     = w.Wn + (size_t)i * w.sW;
+    a.W1b     = a.W1a + (size_t)(2 * w.ma) * w.ldp;
+    a.ldw     = w.ldp;
+    a.wv_out  = w.wv + (size_t)i * 192;
+    a.chain_done = w.done + (size_t)i * kDoneBlock + 256;
+    a.seq        = w.seq;
+    a.timeout    = w.timeout;
+    a.flags      = w.flags + 2 * i;
+    a.stamps     = nullptr;
+    return a;
 }
 
 } // namespace cslam

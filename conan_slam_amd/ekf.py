@@ -217,3 +217,83 @@ class EKF:
             check(self._L.cslam_ekf_debug_last_update(self._h, _vp(out["PHT"]), _vp(out["S"]), _vp(out["G"]),
                                                       _vp(out["W1"]), _vp(out["V"]), C.byref(C.c_int(0))))
         return out
+
+
+class EKFBatch:
+    """`instances` independent f32 filters of `n_landmarks` landmarks each, advancing in lockstep (cslam_ekf_batch_*):
+    the Monte-Carlo unit of BASELINE configs[4] (test/main.cpp:132-200 x I) with one launch per stage for all
+    instances."""
+
+    def __init__(self, instances: int, n_landmarks: int, device: int = -1, quirks: int = Q_REF_EXACT):
+        self._L = _capi.lib()
+        self._h = C.c_void_p(None)
+        check(self._L.cslam_ekf_batch_create(C.c_int(instances), C.c_int(n_landmarks), C.c_int(device), C.c_int(quirks),
+                                             C.byref(self._h)))
+        self.instances, self.n_landmarks, self.n = instances, n_landmarks, 3 + 2 * n_landmarks
+        self.quirks = quirks
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.cslam_ekf_batch_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_state(self, instance: int, X, P):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        P = np.asfortranarray(P, dtype=np.float32)
+        if X.shape != (self.n,) or P.shape != (self.n, self.n):
+            raise ValueError(f"state of {X.shape} / {P.shape}: the batch holds filters of n = {self.n}")
+        check(self._L.cslam_ekf_batch_set_state(self._h, C.c_int(instance), _vp(X), C.c_int(self.n), _vp(P), C.c_int(self.n)))
+
+    def get_state(self, instance: int):
+        X = np.empty(self.n, dtype=np.float32)
+        P = np.empty((self.n, self.n), dtype=np.float32, order="F")
+        check(self._L.cslam_ekf_batch_get_state(self._h, C.c_int(instance), _vp(X), _vp(P), C.c_int(self.n)))
+        return X, P
+
+    def run(self, steps: int, v, swa, Q, wb: float, dt: float, dZ_ptrs, d_idf_ptrs, m: int, R):
+        """steps x {predict; update} on every instance.  v / swa: `steps` controls (common to the instances);
+        dZ_ptrs / d_idf_ptrs: one device pointer per instance (steps x 2m float32 / steps x m int32, step-major)."""
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        swa = np.ascontiguousarray(swa, dtype=np.float64)
+        if v.shape[0] < steps or swa.shape[0] < steps or len(dZ_ptrs) != self.instances or len(d_idf_ptrs) != self.instances:
+            raise ValueError("run: controls shorter than `steps`, or not one input pointer per instance")
+        Q = np.asfortranarray(Q, dtype=np.float32)
+        R = np.asfortranarray(R, dtype=np.float32)
+        zs = (C.c_void_p * self.instances)(*[int(p) for p in dZ_ptrs])
+        ids = (C.c_void_p * self.instances)(*[int(p) for p in d_idf_ptrs])
+        check(self._L.cslam_ekf_batch_run(self._h, C.c_int(steps), v.ctypes.data_as(C.POINTER(C.c_double)),
+                                          swa.ctypes.data_as(C.POINTER(C.c_double)), _vp(Q), C.c_double(wb), C.c_double(dt),
+                                          zs, ids, C.c_int(m), _vp(R)))
+
+    def flush(self):
+        check(self._L.cslam_ekf_batch_flush(self._h))
+
+    def synchronize(self):
+        check(self._L.cslam_ekf_batch_synchronize(self._h))
+
+    def trace(self):
+        tr = (C.c_double * self.instances)()
+        check(self._L.cslam_ekf_batch_trace(self._h, tr))
+        return [float(t) for t in tr]
+
+    def factor_status(self):
+        fl = (C.c_int * self.instances)()
+        check(self._L.cslam_ekf_batch_factor_status(self._h, fl))
+        return [int(f) for f in fl]
+
+    def windows(self) -> int:
+        w = C.c_longlong(0)
+        check(self._L.cslam_ekf_batch_info(self._h, None, None, C.byref(w)))
+        return w.value

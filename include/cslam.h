@@ -163,6 +163,30 @@ int cslam_ekf_run_many(cslam_ekf_t* handles, int count, int steps, const double*
                        double wb, double dt, const void* const* dZ, const int* const* d_idf, int m, const void* R,
                        int batch);
 
+/* Batched Monte-Carlo engine (BASELINE configs[4], test/main.cpp:132-200 x I): `instances` INDEPENDENT f32 filters of the
+ * same size (n = 3 + 2 * n_landmarks, fixed) advance in lockstep, every stage of the step ONE launch for all of them
+ * (conan_slam_amd/csrc/cslam_ekf_batch.hip).  The arithmetic per instance is cslam_ekf_update's (batch form with the
+ * predict held back and applied inside the update, look-ahead windows of two updates): an instance's results are bitwise
+ * those of a single handle that runs the same pairs of updates as look-ahead windows.
+ *   run: `steps` x { predict(v[t], swa[t], Q, wb, dt); update(Z_t, R, idf_t, batch) } on every instance; the controls are
+ *        common to the instances (as in cslam_ekf_run_many), dZ[i] / d_idf[i] are instance i's device-resident inputs,
+ *        steps x (2*m floats) and steps x (m ints), step-major; 9 <= m <= 32.  Asynchronous: returns when the work has
+ *        been enqueued.  Feature indices are checked on the device (CSLAM_FACTOR_BAD_IDF).
+ *   flush applies the pending covariance panels; get_state / trace flush and synchronise; factor_status synchronises and
+ *   writes one flag word per instance.  instances * (round_up(n, 128))^2 * 4 must stay below 4 GiB. */
+typedef struct cslam_ekf_batch* cslam_ekf_batch_t;
+int cslam_ekf_batch_create(int instances, int n_landmarks, int device, int quirks, cslam_ekf_batch_t* out);
+int cslam_ekf_batch_destroy(cslam_ekf_batch_t h);
+int cslam_ekf_batch_set_state(cslam_ekf_batch_t h, int instance, const float* X, int n, const float* P, int ldp);
+int cslam_ekf_batch_get_state(cslam_ekf_batch_t h, int instance, float* X, float* P, int ldp);
+int cslam_ekf_batch_run(cslam_ekf_batch_t h, int steps, const double* v, const double* swa, const float* Q, double wb,
+                        double dt, const float* const* dZ, const int* const* d_idf, int m, const float* R);
+int cslam_ekf_batch_flush(cslam_ekf_batch_t h);
+int cslam_ekf_batch_synchronize(cslam_ekf_batch_t h);
+int cslam_ekf_batch_trace(cslam_ekf_batch_t h, double* traces /* [instances] */);
+int cslam_ekf_batch_factor_status(cslam_ekf_batch_t h, int* flags /* [instances] */);
+int cslam_ekf_batch_info(cslam_ekf_batch_t h, int* instances, int* n, long long* windows);
+
 /* Per-stage device times of update() measured with HIP events on the handle's streams.
  * on = 1 starts recording (events around every stage of every update), on = 2 brackets the covariance downdate
  * (P-GEMM) launches only, on = 3 one downdate launch in sixteen, on = 4 one in four (an event pair costs ~11 us of

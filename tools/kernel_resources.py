@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     out = "/tmp/cslam_kernels.s"
-    for src in ("cslam_ekf.hip", "cslam_pf.hip"):
+    for src in ("cslam_ekf.hip", "cslam_ekf_batch.hip", "cslam_pf.hip"):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
                         os.path.join(ROOT, "conan_slam_amd", "csrc", src)], check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
