@@ -73,6 +73,9 @@ def parse_args():
                     help="cslam_ekf_set_deferred: pending W1 columns applied by one P-GEMM (0 = every update at once; "
                          "default: 128 for batches of 32 observations -- one P-GEMM per two updates --, else 0)")
     ap.add_argument("--instances", type=int, default=8, help="mc: filter instances per GPU")
+    ap.add_argument("--mc-lanes", type=int, default=1, help="mc, batched engine: split the instances into this many batches")
+    ap.add_argument("--mc-engine", choices=["auto", "batch", "handles"], default="auto",
+                    help="mc: batched engine (cslam_ekf_batch_*; f32, 9 <= m <= 32) or one handle + host thread per run")
     ap.add_argument("--pgemm-wgs", type=int, default=-1,
                     help="mc: cap on each instance's persistent P-GEMM grid (-1 / 0: whole chip)")
     ap.add_argument("--particles", type=int, default=512)
@@ -708,6 +711,8 @@ def mc_main(args):
     quirks = Q_TEXTBOOK if args.quirks == "textbook" else Q_REF_EXACT
     total = args.warmup + args.steps
     L = _capi.lib()
+    if args.mc_engine == "batch" or (args.mc_engine == "auto" and args.dtype == "f32" and 9 <= m <= 32 and I >= 2):
+        return mc_batched(args, rank, local_rank, world, torch, dist, N, m, I, quirks)
     engs, dZs, dIs, n = [], [], [], 3 + 2 * N
     for i in range(I):
         w = Workload(N, m, dtype, seed=100 + rank * I + i)
@@ -811,6 +816,138 @@ def mc_main(args):
         e.close()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, m, dtype, args.dtype, args.quirks, args.cpu_baseline_seconds)
+        out["cpu_baseline"]["note"] = "one instance on one core; the reference would run the 64 instances one after another"
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def mc_batched(args, rank, local_rank, world, torch, dist, N, m, I, quirks):
+    """configs[4] through the batched engine (cslam_ekf_batch_*): the I runs of a GPU advance in lockstep, every stage
+    one launch for all of them; then ONE run alone through a single handle for the concurrency gain."""
+    import ctypes as C
+
+    from conan_slam_amd import EKF, EKFBatch, _capi
+    from conan_slam_amd.synth import Workload
+
+    dtype, n = np.float32, 3 + 2 * N
+    W, K = args.warmup + (args.warmup & 1), args.steps  # (an even warm-up keeps the timed windows whole)
+    total = W + K
+    # lanes: the I runs as `lanes` batches of I / lanes on their own streams (their stages interleave on the GPU)
+    lanes = max(1, args.mc_lanes)
+    if I % lanes:
+        raise SystemExit("--mc-lanes must divide --instances")
+    per = I // lanes
+    bs = [EKFBatch(per, N, device=local_rank, quirks=quirks) for _ in range(lanes)]
+    inps, first = [], None
+    for i in range(I):
+        w = Workload(N, m, dtype, seed=100 + rank * I + i)
+        bs[i // per].set_state(i % per, w.X0, w.P0)
+        if i == 0:
+            first = (w.X0.copy(), w.P0)
+        w.P0 = None
+        inps.append(DeviceInputs(torch, w, total))
+    w0 = Workload(N, m, dtype, seed=0, build_p=False)
+    ctrl = [w0.controls(t) for t in range(2 * total)]
+    v = np.array([c[0] for c in ctrl], dtype=np.float64)
+    sw = np.array([c[1] for c in ctrl], dtype=np.float64)
+
+    def run(t0, count):
+        for li, b in enumerate(bs):
+            mine = inps[li * per:(li + 1) * per]
+            b.run(count, v[t0:], sw[t0:], w0.QE, w0.wb, w0.dt, [x.z(t0) for x in mine], [x.i(t0) for x in mine], m, w0.RE)
+
+    def drain():
+        for b in bs:
+            b.flush()
+        for b in bs:
+            b.synchronize()
+
+    run(0, W)
+    drain()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    for b in bs:
+        b.set_profiling(8)
+    t0 = time.perf_counter()
+    run(W, K)
+    drain()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed = max_over_ranks(torch, dist, elapsed)
+    dd_ms, dd_cnt, flags = 0.0, 0, []
+    for b in bs:
+        ms_, c_ = b.pgemm_time()
+        dd_ms, dd_cnt = dd_ms + ms_, dd_cnt + c_
+        b.set_profiling(0)
+        flags += b.factor_status()
+    if rank != 0:
+        for b in bs:
+            b.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    # one run alone with the whole chip, through a single handle (its best mode at this size: deferral window 128)
+    L = _capi.lib()
+    e = EKF(N, dtype=dtype, device=local_rank, quirks=quirks, sync_mode=False)
+    e.set_state(*first)
+    e.set_deferred(128 if 2 * m == 64 else 0)
+    vs = (C.c_double * (2 * total))(*v)
+    ss = (C.c_double * (2 * total))(*sw)
+    QE, RE = np.asfortranarray(w0.QE), np.asfortranarray(w0.RE)
+
+    def run1(t0, count):
+        hs = (C.c_void_p * 1)(e._h)
+        zs = (C.c_void_p * 1)(inps[0].z(t0))
+        ids = (C.c_void_p * 1)(inps[0].i(t0))
+        _capi.check(L.cslam_ekf_run_many(hs, C.c_int(1), C.c_int(count), C.cast(C.byref(vs, t0 * 8), C.POINTER(C.c_double)),
+                                         C.cast(C.byref(ss, t0 * 8), C.POINTER(C.c_double)), QE.ctypes.data_as(C.c_void_p),
+                                         C.c_double(w0.wb), C.c_double(w0.dt), zs, ids, C.c_int(m),
+                                         RE.ctypes.data_as(C.c_void_p), C.c_int(1)))
+        e.flush()
+        e.synchronize()
+
+    run1(0, W)
+    t1 = time.perf_counter()
+    run1(W, K)
+    el1 = time.perf_counter() - t1
+    e.close()
+    k_launch = 4 * m  # two updates' panels per launch
+    dd_s = dd_ms / dd_cnt * 1e-3 if dd_cnt else None
+    rec = roofline_record(n, k_launch, "f32", "lower", dd_s / per if dd_s else None, dd_cnt, N,
+                          {"note": f"ONE launch applies the pending panels of all {per} instances of a batch (ekf_downdate_psym4_f32, BATCH "
+                                   "mode, tickets over the union of their tiles); bytes, flops and roof times are the launch's, "
+                                   f"i.e. {per} x one instance's"})
+    rec["launch_us"] = dd_s * 1e6 if dd_s else None
+    rec["algorithmic_bytes_per_launch"] *= per
+    rec["n_sym_tiles"] *= per
+    rec["roof_times_us"] = {k_: t_ * per for k_, t_ in rec["roof_times_us"].items()}
+    rec["traffic"], rec["traffic_source"] = None, None
+    out = {
+        "metric": "ekf_update_steps_per_sec", "value": world * I * K / elapsed, "unit": "update steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{world * I} independent Monte-Carlo EKF-SLAM runs x {N} landmarks (n={n}), m={m} (k={2 * m}), "
+                               f"f32, {I} runs per GPU in lockstep through the batched engine (one launch per stage)",
+                   "landmarks": N, "n": n, "obs_per_update": m, "instances_per_gpu": I, "batches_per_gpu": lanes,
+                   "gain_algebra": args.quirks,
+                   "engine": "cslam_ekf_batch (look-ahead windows of two updates, one launch per stage for all instances)",
+                   "parallelism": f"{I} instances/GPU x {world} GPU(s), no collective",
+                   "baseline_config": "BASELINE.json configs[4]" if N == 2000 else "custom"},
+        "single_instance": {"value": K / el1, "unit": "update steps/s", "ms_per_step": el1 / K * 1e3,
+                            "note": "instance 0 run alone on the same GPU through a single handle (cslam_ekf_run_many, "
+                                    "deferral window 128)"},
+        "concurrency_gain": (I * K / elapsed) / (K / el1) if world == 1 else None,
+        "roofline": rec,
+        "factor_flags": flags,
+    }
+    for b in bs:
+        b.close()
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, m, dtype, "f32", args.quirks, args.cpu_baseline_seconds)
         out["cpu_baseline"]["note"] = "one instance on one core; the reference would run the 64 instances one after another"
     print(json.dumps(out), flush=True)
     if dist is not None:

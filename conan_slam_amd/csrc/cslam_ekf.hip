@@ -38,7 +38,7 @@ namespace cslam
 // the wide half of a look-ahead window (ekf_lookahead.hpp: ekf_la_wide_body), one filter
 __global__ void __launch_bounds__(128) ekf_la_wide_f32(LaWideArgs a)
 {
-    ekf_la_wide_body(a);
+    ekf_la_wide_body<1>(a);
 }
 } // namespace cslam
 

@@ -16,7 +16,9 @@
 // pending store W [2 regions][I][128][ldp] (P = Ps - Wp Wp^T, Wp = the previous window's panels), factor slots, the
 // look-ahead scratch and the wait counters (labatch:: layout in ekf_lookahead.hpp).
 #include <algorithm>
+#include <cstdlib>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "cslam_common.hpp"
@@ -46,12 +48,26 @@ __global__ void __launch_bounds__(256) ekf_la_chain_batch(LaBatchWin w)
     const LaChainArgs<float> a = la_batch_chain(w, blockIdx.x); // (one workgroup per instance)
     ekf_la_chain_body<float, K>(a);
 }
-__global__ void __launch_bounds__(128) ekf_la_wide_batch(LaBatchWin w)
+__global__ void __launch_bounds__(128) ekf_la_wide_batch1(LaBatchWin w) // (A/B: CSLAM_BATCH_WIDE_PAIRS=1)
 {
     const LaWideArgs a = la_batch_wide(w, blockIdx.y);
-    ekf_la_wide_body(a);
+    ekf_la_wide_body<1>(a);
+}
+// (two pairs of waves per workgroup, 256 registers: 8 waves per compute unit instead of 4, see ekf_la_wide_body)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_la_wide_batch(LaBatchWin w)
+{
+    const LaWideArgs a = la_batch_wide(w, blockIdx.y);
+    ekf_la_wide_body<2>(a);
 }
 
+// windows without a P-GEMM (nothing pending): the chains' go-ahead as a kernel of its own
+__global__ void __launch_bounds__(256) ekf_la_signal_batch(unsigned* signal, unsigned add, int count, int stride)
+{
+    if ((int)threadIdx.x < count)
+    {
+        atomicAdd(signal + (size_t)threadIdx.x * stride, add);
+    }
+}
 } // namespace cslam
 
 struct cslam_ekf_batch
@@ -64,14 +80,22 @@ struct cslam_ekf_batch
     const float** dZtab   = nullptr; // [2][I] (two generations: a run() may be enqueued while the previous one executes)
     const int**   dIdftab = nullptr;
     int           tab_gen = 0;
-    std::vector<const float*> hZ[2]; // host copies of the tables (the source of a stream-ordered copy must stay put)
-    std::vector<const int*>   hI[2];
+    hipEvent_t    ev_gen[2]   = {nullptr, nullptr}; // the last kernel that reads generation g has finished
+    bool          gen_used[2] = {false, false};
     int2*         dTiles  = nullptr;
     int*          dTicket = nullptr;
     int           n_tiles = 0, parity = 0;
     int           wcur = 0, kp = 0; // pending region and its columns
     unsigned      target = 0, seq = 0;
     long long     windows = 0;
+    // A/B switches (env CSLAM_BATCH_WG_SIGNAL=1, CSLAM_BATCH_WIDE_PAIRS=1): the first forms of two stages, kept measurable
+    int wg_signal = 0, wide_pairs = 2;
+    long long* dStamps = nullptr; // CSLAM_BATCH_STAMPS=1: see LaBatchWin::stamps (printed after 300 windows)
+    // bench support: HIP events around one P-GEMM launch in `prof_every` (an event pair costs ~11 us of stream time)
+    int                                          prof_every = 0;
+    long long                                    prof_seen  = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    size_t                                       prof_used = 0;
 
     static constexpr int kWcols = 128; // columns per instance and region: one window's panels
 
@@ -117,6 +141,21 @@ struct cslam_ekf_batch
         (void)hipFree(dIdftab);
         (void)hipFree(dTiles);
         (void)hipFree(dTicket);
+        (void)hipFree(dStamps);
+        for (auto& e : prof_ev)
+        {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        prof_ev.clear();
+        for (hipEvent_t& e : ev_gen)
+        {
+            if (e)
+            {
+                (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+        }
         if (stream)
         {
             (void)hipStreamDestroy(stream);
@@ -134,6 +173,19 @@ struct cslam_ekf_batch
         {
             return rc;
         }
+        if (const char* e = getenv("CSLAM_BATCH_WG_SIGNAL"))
+        {
+            wg_signal = atoi(e) ? 1 : 0;
+        }
+        if (const char* e = getenv("CSLAM_BATCH_WIDE_PAIRS"))
+        {
+            wide_pairs = atoi(e) == 1 ? 1 : 2;
+        }
+        if (getenv("CSLAM_BATCH_STAMPS"))
+        {
+            CSLAM_HIP_TRY(hipMalloc(&dStamps, 32 * sizeof(long long)));
+            CSLAM_HIP_TRY(hipMemset(dStamps, 0, 32 * sizeof(long long)));
+        }
         hipDeviceProp_t prop;
         CSLAM_HIP_TRY(hipGetDeviceProperties(&prop, device));
         num_cus = prop.multiProcessorCount;
@@ -145,6 +197,8 @@ struct cslam_ekf_batch
         CSLAM_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         CSLAM_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         CSLAM_HIP_TRY(hipStreamCreateWithPriority(&stream_f, hipStreamNonBlocking, hi));
+        CSLAM_HIP_TRY(hipEventCreateWithFlags(&ev_gen[0], hipEventDisableTiming));
+        CSLAM_HIP_TRY(hipEventCreateWithFlags(&ev_gen[1], hipEventDisableTiming));
         const size_t L = (size_t)ldp;
         CSLAM_HIP_TRY(hipMalloc(&dX, I * L * sizeof(float)));
         CSLAM_HIP_TRY(hipMalloc(&dPv, I * 3 * L * sizeof(float)));
@@ -203,11 +257,17 @@ struct cslam_ekf_batch
         return CSLAM_OK;
     }
 
-    // P -= Wp Wp^T of every instance: one persistent launch over the union tile list
-    int flush()
+    // P -= Wp Wp^T of every instance: one persistent launch over the union tile list.  sig_add != 0: the launch also tells
+    // the waiting factor chains that the blocks kernel in front of it has finished (see ekf_la_blocks_body).
+    int flush(unsigned sig_add = 0)
     {
         if (kp == 0)
         {
+            if (sig_add)
+            {
+                hipLaunchKernelGGL(ekf_la_signal_batch, dim3(1), dim3(256), 0, stream, dDone, sig_add, I, labatch::kDoneBlock);
+                CSLAM_HIP_TRY(hipGetLastError());
+            }
             return CSLAM_OK;
         }
         float*    W     = wregion(wcur);
@@ -224,10 +284,16 @@ struct cslam_ekf_batch
         const unsigned p_span = (unsigned)((size_t)I * ldp * ldp * 4);
         const unsigned w_span = (unsigned)((size_t)I * sW() * 4);
         parity ^= 1;
+        const bool timed = prof_every > 0 && (prof_seen++ % prof_every) == 0 && prof_used < prof_ev.size();
+        if (timed)
+        {
+            CSLAM_HIP_TRY(hipEventRecord(prof_ev[prof_used].first, stream));
+        }
 #define CSLAM_LAUNCH_PSYM4B(NCH, KC)                                                                                  \
     hipLaunchKernelGGL((ekf_downdate_psym4_f32<0, NCH, KC, false, true>), dim3(G), dim3(256), 0, stream, dP, ldp, W, ldp, \
                        kp, (const int2*)dTiles, n_tiles, dTicket + parity, dTicket + (parity ^ 1),                  \
-                       (unsigned long long*)nullptr, (const int*)nullptr, sPb, sWb, p_span, w_span)
+                       (unsigned long long*)nullptr, (const int*)nullptr, sPb, sWb, p_span, w_span,                   \
+                       sig_add ? dDone : (unsigned*)nullptr, sig_add, I, (int)labatch::kDoneBlock)
         if (k8 <= 64)
         {
             CSLAM_LAUNCH_PSYM4B(2, 32);
@@ -242,6 +308,10 @@ struct cslam_ekf_batch
         }
 #undef CSLAM_LAUNCH_PSYM4B
         CSLAM_HIP_TRY(hipGetLastError());
+        if (timed)
+        {
+            CSLAM_HIP_TRY(hipEventRecord(prof_ev[prof_used++].second, stream));
+        }
         wcur ^= 1;
         kp = 0;
         return CSLAM_OK;
@@ -272,6 +342,9 @@ struct cslam_ekf_batch
         w.kp       = kp;
         w.target   = target + n_blocks;
         w.seq      = ++seq;
+        w.wg_signal = wg_signal;
+        w.wide_direct = getenv("CSLAM_BATCH_TIMING_DIRECT") ? 1 : 0;
+        w.stamps      = dStamps;
         w.timeout  = 20000000ull; // 0.2 s of s_memrealtime ticks: a stuck wait raises CSLAM_FACTOR_INTERNAL instead of hanging
         // 1. the factor chains first: each takes a compute unit and waits there for its instance's blocks
         if (std::max(ka, kb) <= 32)
@@ -288,8 +361,9 @@ struct cslam_ekf_batch
         hipLaunchKernelGGL(ekf_la_blocks_batch, dim3(n_blocks, I), dim3(64), 0, stream, w);
         CSLAM_HIP_TRY(hipGetLastError());
         target += n_blocks;
-        // 3. the P-GEMM of the previous window's panels: the chains run underneath it
-        int rc = flush();
+        // 3. the P-GEMM of the previous window's panels: its first workgroup gives the chains their go-ahead (the blocks
+        //    kernel has finished by then), and they run underneath it
+        int rc = flush(wg_signal ? 0u : n_blocks);
         if (rc)
         {
             return rc;
@@ -297,10 +371,26 @@ struct cslam_ekf_batch
         // 4. the wide half of both updates (waits in the kernel for its instance's chain); its W1 panels become the pending
         //    columns of the region the P-GEMM has just left
         w.Wn = wregion(wcur);
-        hipLaunchKernelGGL(ekf_la_wide_batch, dim3(round_up(n, kTile) / 32, I), dim3(128), 0, stream, w);
+        if (wide_pairs == 1)
+        {
+            hipLaunchKernelGGL(ekf_la_wide_batch1, dim3(round_up(n, kTile) / 32, I), dim3(128), 0, stream, w);
+        }
+        else
+        {
+            hipLaunchKernelGGL(ekf_la_wide_batch, dim3(round_up(n, kTile) / 64, I), dim3(256), 0, stream, w);
+        }
         CSLAM_HIP_TRY(hipGetLastError());
         kp = ka + kb;
         windows++;
+        if (dStamps && windows == 300)
+        {
+            long long h[32];
+            CSLAM_HIP_TRY(hipStreamSynchronize(stream));
+            CSLAM_HIP_TRY(hipMemcpy(h, dStamps, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[cslam batch wide stamps, 10 ns ticks] ids+columns issue:%lld poll+DMA wait:%lld pht_a:%lld gain_a:%lld "
+                            "store+share W1_a:%lld pht_b+corr:%lld share+G_b:%lld gain_b:%lld store_b:%lld\n",
+                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[9] - h[8]);
+        }
         return CSLAM_OK;
     }
 };
@@ -527,20 +617,19 @@ int cslam_ekf_batch_run(cslam_ekf_batch_t h, int steps, const double* v, const d
     {
         return rc;
     }
-    // the per-instance input pointers of this call (stream-ordered copy into the generation the previous call does not use)
+    // The per-instance input pointers of this call go into the table generation the previous call does not use, with a
+    // BLOCKING copy: the chain kernels read them on stream F, which is not ordered behind copies on the main stream.  The
+    // generation was last used two calls ago: wait for that call's last kernel (the call in between stays in flight).
     h->tab_gen ^= 1;
-    const float** zt = h->dZtab + (size_t)h->tab_gen * h->I;
-    const int**   it = h->dIdftab + (size_t)h->tab_gen * h->I;
-    if (h->tab_gen == 0)
+    const int     g  = h->tab_gen;
+    const float** zt = h->dZtab + (size_t)g * h->I;
+    const int**   it = h->dIdftab + (size_t)g * h->I;
+    if (h->gen_used[g])
     {
-        // (the host copies of generation 0 are about to be rewritten: whatever still reads them must have finished --
-        // one wait per pair of calls)
-        CSLAM_HIP_TRY(hipStreamSynchronize(h->stream));
+        CSLAM_HIP_TRY(hipEventSynchronize(h->ev_gen[g]));
     }
-    h->hZ[h->tab_gen].assign(dZ, dZ + h->I);
-    h->hI[h->tab_gen].assign(d_idf, d_idf + h->I);
-    CSLAM_HIP_TRY(hipMemcpyAsync(zt, h->hZ[h->tab_gen].data(), (size_t)h->I * sizeof(float*), hipMemcpyHostToDevice, h->stream));
-    CSLAM_HIP_TRY(hipMemcpyAsync(it, h->hI[h->tab_gen].data(), (size_t)h->I * sizeof(int*), hipMemcpyHostToDevice, h->stream));
+    CSLAM_HIP_TRY(hipMemcpy(zt, dZ, (size_t)h->I * sizeof(float*), hipMemcpyHostToDevice));
+    CSLAM_HIP_TRY(hipMemcpy(it, d_idf, (size_t)h->I * sizeof(int*), hipMemcpyHostToDevice));
     const int pw = (h->quirks & CSLAM_Q_PREDICT_NM4) ? (h->n - 4) : (h->n - 3);
     auto      pp = [&](int t) {
         return PredictArgs<float>{1, (float)v[t], (float)swa[t], Q[0], Q[1], Q[2], Q[3], (float)wb, (float)dt, std::max(pw, 0)};
@@ -569,6 +658,55 @@ int cslam_ekf_batch_run(cslam_ekf_batch_t h, int steps, const double* v, const d
             return rc;
         }
     }
+    CSLAM_HIP_TRY(hipEventRecord(h->ev_gen[g], h->stream)); // (the chains of a window finish before its wide kernel does)
+    h->gen_used[g] = true;
+    return CSLAM_OK;
+}
+
+int cslam_ekf_batch_set_profiling(cslam_ekf_batch_t h, int every)
+{
+    if (!h || every < 0)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "ekf_batch_set_profiling: bad arguments");
+    }
+    int rc = h->use_device();
+    if (rc || (rc = h->sync()))
+    {
+        return rc;
+    }
+    h->prof_every = every;
+    h->prof_seen  = 0;
+    h->prof_used  = 0;
+    while (every > 0 && h->prof_ev.size() < 256)
+    {
+        hipEvent_t a = nullptr, b = nullptr;
+        CSLAM_HIP_TRY(hipEventCreate(&a));
+        CSLAM_HIP_TRY(hipEventCreate(&b));
+        h->prof_ev.push_back({a, b});
+    }
+    return CSLAM_OK;
+}
+
+int cslam_ekf_batch_get_pgemm_time(cslam_ekf_batch_t h, double* ms_sum, int* launches)
+{
+    if (!h || !ms_sum || !launches)
+    {
+        return fail(CSLAM_ERR_BAD_ARG, "ekf_batch_get_pgemm_time: bad arguments");
+    }
+    int rc = h->use_device();
+    if (rc || (rc = h->sync()))
+    {
+        return rc;
+    }
+    double s = 0.0;
+    for (size_t i = 0; i < h->prof_used; i++)
+    {
+        float ms = 0.f;
+        CSLAM_HIP_TRY(hipEventElapsedTime(&ms, h->prof_ev[i].first, h->prof_ev[i].second));
+        s += ms;
+    }
+    *ms_sum   = s;
+    *launches = (int)h->prof_used;
     return CSLAM_OK;
 }
 

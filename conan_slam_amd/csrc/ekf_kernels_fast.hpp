@@ -2315,8 +2315,19 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
                        const int2* __restrict__ tile_list_in, int ntiles_in, int* __restrict__ ticket_in,
                        int* __restrict__ ticket_reset, unsigned long long* __restrict__ hwids,
                        const int* __restrict__ seg_off = nullptr, unsigned sP = 0, unsigned sW = 0, unsigned p_span = 0,
-                       unsigned w_span = 0)
+                       unsigned w_span = 0, unsigned* __restrict__ signal = nullptr, unsigned sig_add = 0, int sig_count = 0,
+                       int sig_stride = 0)
 {
+    // BATCH: the kernels launched before this one on the stream have finished and their results are visible device-wide
+    // (kernel boundary): tell the `sig_count` factor chains that wait for them (ekf_la_chain_batch; one counter each).
+    // One atomic per instance here replaces a release fence + atomic in every workgroup of the blocks kernel.
+    if constexpr (BATCH)
+    {
+        if (signal != nullptr && blockIdx.x == 0 && (int)threadIdx.x < sig_count)
+        {
+            atomicAdd(signal + (size_t)threadIdx.x * sig_stride, sig_add);
+        }
+    }
     // seg_off != nullptr: one tile queue per XCD.  tile_list_in is then Morton-ordered and cut into eight segments
     // (seg_off[0..8]), ticket_in / ticket_reset are eight counters each, and workgroup b works on queue b & 7 -- its
     // first two tiles by its rank b >> 3 in that queue, the rest by tickets -- exactly as on the single queue.  Blocks

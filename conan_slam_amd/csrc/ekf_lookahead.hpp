@@ -386,7 +386,13 @@ __device__ __forceinline__ void ekf_la_blocks_body(const LaPrepArgs<T>& a)
             a.PvLb[s * 3 + tid] = s_e3[tid];
         }
     }
-    // this workgroup's rows are out: release them to the chain kernel (device scope: it may run on another XCD)
+    // this workgroup's rows are out: release them to the chain kernel (device scope: it may run on another XCD).
+    // (done == nullptr: the batched engine signals its chains from the NEXT kernel on the stream instead -- a release fence
+    // writes back the unit's L2, and 8 instances x 195 workgroups of them took 24 us against 8 us for one instance)
+    if (a.done == nullptr)
+    {
+        return;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0)
@@ -873,32 +879,40 @@ __device__ __forceinline__ int la_q_of(int t, int r, int lh)
     return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
 }
 
+// PAIRS: pairs of waves per workgroup (1: the single filter's kernel; 2: the batched engine's -- two blocks of 32 rows share
+// ONE copy of the staged factor outputs, so that twice the waves fit a compute unit: the batch has ~1000 blocks of rows
+// where a single filter has ~300).
+template <int PAIRS = 1>
 __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
 {
     // TWO waves per block of 32 rows.  Wave w owns column tile w (32 columns) of every product -- half the matrix-core
     // chain, half the operand reads -- and builds tile w of PHT; the halves meet through LDS (one 8 KB exchange area,
     // carved out of the G areas while they are not in use).  The wave's work is one dependent chain, so every global
     // read is issued as early as its address is known:
-    //   round 1: the small shared inputs, this row's stripe entries, and G_a^T, Y_b straight into LDS by LDS-DMA
+    //   round 0: the feature ids, this row's stripe entries, then the landmark columns of Ps for BOTH updates (their
+    //            addresses need the feature ids) -- the longest round trip of the kernel (scattered, cold);
+    //   round 1: once the chain has been seen finished: G_a^T, Y_b and the small shared inputs straight into LDS by LDS-DMA
     //            (no registers in between: 16 KB each, one 1 KB piece per instruction); G_b^T follows once the exchange
-    //            area has moved out of its space;
-    //   round 2: the landmark columns of Ps for BOTH updates (their addresses need the feature ids of round 1).
-    // After that the kernel computes from registers and LDS only.
+    //            area has moved out of its space.
+    // After that the kernel computes from registers and LDS only.  (Measured on the batched engine: issuing the poll with
+    // round 0, or the DMA before the columns, does not help -- the column round trip, 12-18 us under load, is the floor.)
     __shared__ __attribute__((aligned(16))) float s_G[2][4 * 1024]; // G^T of a / b, as in memory: [q * k + c]
     __shared__ __attribute__((aligned(16))) float s_Y[4 * 1024];    // Y_b: [c * kb + q]
     __shared__ __attribute__((aligned(16))) float s_model[2][512];  // LaModel image: {g02, g12, pose, pvv} then coef at 14
     __shared__ __attribute__((aligned(16))) float s_u[2][256];
     __shared__ __attribute__((aligned(16))) float s_M[2][256];
     __shared__ int   s_fx[2][kLaMaxObs];
-    __shared__ float s_sum[4][32];
-    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lj = lane & 31, lh = lane >> 5;
-    const int row0 = blockIdx.x * 32;
+    __shared__ float s_sum_all[PAIRS][4][32];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lj = lane & 31, lh = lane >> 5;
+    const int wv = wave & 1, pr = wave >> 1; // column tile of this wave; its pair (block of rows) within the workgroup
+    float (*s_sum)[32] = s_sum_all[pr];
+    const int row0 = (blockIdx.x * PAIRS + pr) * 32;
     const int row  = row0 + lj;
     const int rowc = row < a.n ? row : a.n - 1;
     const int ka = 2 * a.ma, kb = 2 * a.mb;
     int       stamp_i = 0;
     auto      stamp   = [&]() {
-        if (a.stamps != nullptr && blockIdx.x == 100 && tid == 0)
+        if (a.stamps != nullptr && blockIdx.x == (gridDim.x >> 1) && tid == 0)
         {
             a.stamps[stamp_i++] = (long long)__builtin_amdgcn_s_memrealtime();
         }
@@ -978,7 +992,7 @@ __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
         it               = it < pieces ? it : 0;
         for (int j = 0; j < pieces; j++, it = (it + 1 < pieces) ? it + 1 : 0)
         {
-            if ((j & 1) == wv)
+            if ((j % (2 * PAIRS)) == wave)
             {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + it * 256), 16, (unsigned)(lane * 16),
                                                          (unsigned)(it * 1024), 0, 0);
@@ -1000,7 +1014,7 @@ __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
     __syncthreads();
     stamp();
     // exchange area (16 registers x 64 lanes per tile): in G_b's space until G_b is staged, then in G_a's
-    float* xch = s_G[1];
+    float* xch = s_G[1] + pr * 2048;
     float  own[16];  // this wave's tile of the row vector in hand (PHT or W1), accumulator layout
     float  full[32]; // both tiles
     auto share = [&]() { // own -> LDS, then both tiles back
@@ -1200,7 +1214,7 @@ __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
         // the exchange area moves into G_a's space (dead since gain a); G_b is staged into its own
         __syncthreads(); // (everybody is done with W1_a in the old exchange area)
         dma(a.Gt_b, kb * kb, s_G[1]);
-        xch = s_G[0];
+        xch = s_G[0] + pr * 2048;
         share();
         __builtin_amdgcn_s_waitcnt(0x0F70); // G_b has landed ...
         __syncthreads();                    // ... for both waves; the row sums of update a have been read by everybody
@@ -1288,6 +1302,9 @@ struct LaBatchWin
     const int* const*   idftab;
     long zoff_a, zoff_b, ioff_a, ioff_b; // element offsets of update a / b in each instance's arrays
     int  ma, mb, nu;
+    long long* stamps; // diagnostics (CSLAM_BATCH_STAMPS): phase stamps of one workgroup of instance 0's wide kernel
+    int  wide_direct; // timing experiment only (wrong results): the wide kernel reads P(row, col) where it lies, no mirroring
+    int  wg_signal; // 1: every workgroup of the blocks kernel releases its rows itself (A/B switch of the batched engine)
     PredictArgs<float> pp_a, pp_b;
     float R[4];
     int   kp;
@@ -1348,7 +1365,7 @@ __device__ __forceinline__ LaPrepArgs<float> la_batch_prep(const LaBatchWin& w, 
     a.model_a = reinterpret_cast<LaModel<float>*>(la + kModel);
     a.xloc_a  = fo + kXloc;
     a.idloc   = w.idloc + kLaMaxObs * i;
-    a.done    = w.done + (size_t)i * kDoneBlock;
+    a.done    = w.wg_signal ? w.done + (size_t)i * kDoneBlock : nullptr; // (0: signalled by the kernel that follows)
     return a;
 }
 
@@ -1438,7 +1455,7 @@ __device__ __forceinline__ LaWideArgs la_batch_wide(const LaBatchWin& w, int i)
     a.P       = w.P + (size_t)i * w.ldp * w.ldp;
     a.ldp     = w.ldp;
     a.n       = w.n;
-    a.lower   = w.lower;
+    a.lower   = w.wide_direct ? 0 : w.lower;
     a.X       = w.X + (size_t)i * w.ldp;
     a.Pv      = w.Pv + (size_t)i * 3 * w.ldp;
     a.nu      = w.nu;
@@ -1469,7 +1486,7 @@ __device__ __forceinline__ LaWideArgs la_batch_wide(const LaBatchWin& w, int i)
     a.seq        = w.seq;
     a.timeout    = w.timeout;
     a.flags      = w.flags + 2 * i;
-    a.stamps     = nullptr;
+    a.stamps     = i == 0 ? w.stamps : nullptr;
     return a;
 }
 

@@ -297,3 +297,12 @@ class EKFBatch:
         w = C.c_longlong(0)
         check(self._L.cslam_ekf_batch_info(self._h, None, None, C.byref(w)))
         return w.value
+
+    def set_profiling(self, every: int):
+        check(self._L.cslam_ekf_batch_set_profiling(self._h, C.c_int(every)))
+
+    def pgemm_time(self):
+        """(sum of ms, launches) of the covariance-downdate launches timed since set_profiling(every > 0)."""
+        ms, cnt = C.c_double(0.0), C.c_int(0)
+        check(self._L.cslam_ekf_batch_get_pgemm_time(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

@@ -186,6 +186,10 @@ int cslam_ekf_batch_synchronize(cslam_ekf_batch_t h);
 int cslam_ekf_batch_trace(cslam_ekf_batch_t h, double* traces /* [instances] */);
 int cslam_ekf_batch_factor_status(cslam_ekf_batch_t h, int* flags /* [instances] */);
 int cslam_ekf_batch_info(cslam_ekf_batch_t h, int* instances, int* n, long long* windows);
+/* HIP events around one covariance-downdate launch in `every` (0 stops; at most 256 launches are kept; synchronises);
+ * get: synchronises, sum of milliseconds and number of the launches timed since profiling was switched on. */
+int cslam_ekf_batch_set_profiling(cslam_ekf_batch_t h, int every);
+int cslam_ekf_batch_get_pgemm_time(cslam_ekf_batch_t h, double* ms_sum, int* launches);
 
 /* Per-stage device times of update() measured with HIP events on the handle's streams.
  * on = 1 starts recording (events around every stage of every update), on = 2 brackets the covariance downdate
