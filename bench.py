@@ -43,7 +43,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TF = {"f32": 157.3, "f64": 78.6}
+# dense matrix-core peaks the P-GEMMs are priced against.  f32: the datasheet's 157.3 TF (v_mfma_f32_32x32x2_f32 measured
+# back to back on the box: 152.7 TF).  f64: the MEASURED rate of the instruction the f64 kernels use, v_mfma_f64_16x16x4_f64
+# -- 46.0 TF on all 256 compute units (tools/probes/mfma_peak_probe.hip, profiles/r03_mfma_peak.txt); the datasheet's
+# 78.6 TF is not reachable with it (SURVEY 8d asks for the box's own figure where they differ).
+MFMA_PEAK_TF = {"f32": 157.3, "f64": 46.0}
+MFMA_DATASHEET_TF = {"f32": 157.3, "f64": 78.6}
+MFMA_MEASURED_TF = {"f32": 152.7, "f64": 46.0}
 
 
 def parse_args():
@@ -307,6 +313,9 @@ def roofline_record(n, k_launch, dname, storage, launch_s, launches, landmarks, 
         "n_sym_tiles": md["n_sym_tiles"],
         "launch_us": launch_s * 1e6 if launch_s else None, "launches_timed": launches, "k_per_launch": k_launch,
         "mfma_tflops_issued": tf, "mfma_frac_of_peak": (tf / mfma_peak) if tf else None,
+        "mfma_peaks_tf": {"priced_against": mfma_peak, "datasheet": MFMA_DATASHEET_TF.get(dname),
+                          "measured_back_to_back": MFMA_MEASURED_TF.get(dname),
+                          "source": "tools/probes/mfma_peak_probe.hip, profiles/r03_mfma_peak.txt"},
         "mfma_flops_model": "issued: tiles x 128^2 x (32-column chunks x 32) x 2 (a symmetric kernel issues ~n^2 k, not 2 n^2 k)",
         # SURVEY 8d's full-storage formula for the same launch: what a non-symmetric implementation would have to
         # move; NOT a fraction of anything this kernel does
