@@ -163,7 +163,10 @@ __global__ void __launch_bounds__(256) ekf_pose_step_kernel(T* __restrict__ X, T
                     {
                         val = pvv[r + 3 * cc] - (pcol[r] * si) * prow[cc];
                     }
-                    nv[r + 3 * cc] = val;
+                    // + I * FLT_MIN (slam.h:719): the reference's driver starts from P = 0, which this keeps at FLT_MIN * I.
+                    // Only the pose block carries it here: a map diagonal entry absorbs 1.2e-38 in rounding unless it is
+                    // below 2^-102 (deliberate deviation)
+                    nv[r + 3 * cc] = val + ((r == cc) ? (T)1.17549435e-38f : (T)0);
                 }
             }
 #pragma unroll

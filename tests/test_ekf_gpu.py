@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from helpers import OracleState, P_RTOL, X_RTOL, assert_close, make_obs, make_scenario
-from pyoracle import REF_EXACT, TEXTBOOK
+from pyoracle import Oracle, REF_EXACT, TEXTBOOK
 
 pytestmark = pytest.mark.gpu
 
@@ -207,6 +207,26 @@ def test_bad_feature_index_is_refused(gpu_required):
     with pytest.raises(CslamError) as ei:
         eng.update(np.array([[10.0], [0.1]], np.float32), np.eye(2, dtype=np.float32), np.array([4], np.int32), True)
     assert ei.value.code == _capi.ERR_BAD_ARG
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_observe_heading_from_the_drivers_zero_covariance(gpu_required, dtype):
+    """The reference's driver starts from X = 0, P = 0 with no landmarks (test/main.cpp:105-112) and calls observeHeading
+    every control step: slam.h:719 adds I * FLT_MIN, so P becomes exactly FLT_MIN * I and the pose does not move."""
+    from conan_slam_amd import EKF
+
+    eng = EKF(4, dtype=dtype, quirks=REF_EXACT)
+    eng.set_state(np.zeros(3, dtype), np.zeros((3, 3), dtype, order="F"))
+    o = Oracle(dtype, REF_EXACT)
+    X, P = np.zeros(3, dtype), np.zeros((3, 3), dtype, order="F")
+    for step in range(2):
+        eng.observe_heading(0.2, True)
+        o.observe_heading(X, P, 3, 0.2, True)
+    Xg, Pg = eng.get_state()
+    tiny = np.dtype(dtype).type(np.finfo(np.float32).tiny)
+    assert np.array_equal(P, np.eye(3, dtype=dtype) * (tiny + tiny)), P
+    assert np.array_equal(Pg, P) and np.array_equal(Xg, X)
     eng.close()
 
 

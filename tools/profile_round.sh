@@ -11,6 +11,8 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   # headline (look-ahead windows, k = 128 launches) and immediate (k = 64 launches), separate passes per counter set
   timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/k128_$d -o runc -- python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extras > $O/pmc_k128_$d.log 2>&1
   timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/k64_$d -o runc -- python3 $R/bench.py --defer 0 --steps 12 --warmup 3 --no-cpu-baseline --no-extras > $O/pmc_k64_$d.log 2>&1
+  # the batched Monte-Carlo engine's P-GEMM (8 x N = 2000 per launch)
+  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/mc_$d -o runc -- python3 $R/bench.py --workload mc --steps 12 --warmup 4 --no-cpu-baseline > $O/pmc_mc_$d.log 2>&1
   echo "pmc $d done"
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ekf -o run -- python3 $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-extras > $O/stats_ekf.log 2>&1
@@ -31,12 +33,15 @@ cat $O/pmc_summary.txt
 python3 tools/trace_timeline.py $(find $O/stats_ekf -name run_kernel_trace.csv | head -1) 0.6 24 > $O/timeline_lookahead.txt 2>&1 || true
 python3 tools/trace_timeline.py $(find $O/stats_ekf_classic -name run_kernel_trace.csv | head -1) 0.6 24 > $O/timeline_classic.txt 2>&1 || true
 python3 tools/trace_timeline.py $(find $O/stats_f64 -name run_kernel_trace.csv | head -1) 0.6 24 > $O/timeline_f64.txt 2>&1 || true
+python3 tools/trace_timeline.py $(find $O/stats_mc -name run_kernel_trace.csv | head -1) 0.3 24 > $O/timeline_mc_batch.txt 2>&1 || true
+tools/probes/mfma_peak_probe > $O/mfma_peak.txt 2>&1 || true
 python3 bench.py > $O/bench_ekf.json 2> $O/bench.err
 python3 bench.py --no-lookahead --no-cpu-baseline --no-extras > $O/bench_ekf_classic.json 2>> $O/bench.err || true
 python3 bench.py --dtype f64 --landmarks 1000 > $O/bench_f64_n1000.json 2>> $O/bench.err || true
 python3 bench.py --workload pf --force-resample > $O/bench_pf.json 2>> $O/bench.err || true
 python3 bench.py --workload mc > $O/bench_mc.json 2>> $O/bench.err || true
+python3 bench.py --workload mc --mc-engine handles --no-cpu-baseline > $O/bench_mc_handles.json 2>> $O/bench.err || true
 python3 bench.py --sequential --obs 8 --no-cpu-baseline --no-extras > $O/bench_sequential.json 2>> $O/bench.err || true
 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2>> $O/bench.err || true
-for f in bench_ekf bench_ekf_classic bench_f64_n1000 bench_pf bench_mc bench_sequential bench_driver_shape; do python3 -c "
+for f in bench_ekf bench_ekf_classic bench_f64_n1000 bench_pf bench_mc bench_mc_handles bench_sequential bench_driver_shape; do python3 -c "
 import json;d=json.loads(open('$O/$f.json').read().strip().split('\n')[-1]);print('$f', round(d['value']), round(d['ms_per_step'],5), (d.get('roofline') or {}).get('frac'))" || true; done
