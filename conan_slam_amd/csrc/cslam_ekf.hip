@@ -1917,6 +1917,7 @@ struct Ekf : EkfBase
                 wa.timeout    = 20000000ull;
                 wa.flags      = dFlags;
                 wa.stamps     = la_stamps ? la_stamps + 16 : nullptr;
+                wa.wg_times   = nullptr;
                 wa.P       = dP;
                 wa.ldp     = ldp;
                 wa.n       = n;

@@ -183,8 +183,9 @@ struct cslam_ekf_batch
         }
         if (getenv("CSLAM_BATCH_STAMPS"))
         {
-            CSLAM_HIP_TRY(hipMalloc(&dStamps, 32 * sizeof(long long)));
-            CSLAM_HIP_TRY(hipMemset(dStamps, 0, 32 * sizeof(long long)));
+            // 32 phase stamps, then {start, end} of up to 128 wide-kernel workgroups per instance
+            CSLAM_HIP_TRY(hipMalloc(&dStamps, (32 + (size_t)I * 256) * sizeof(long long)));
+            CSLAM_HIP_TRY(hipMemset(dStamps, 0, (32 + (size_t)I * 256) * sizeof(long long)));
         }
         hipDeviceProp_t prop;
         CSLAM_HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -390,6 +391,35 @@ struct cslam_ekf_batch
             fprintf(stderr, "[cslam batch wide stamps, 10 ns ticks] ids+columns issue:%lld poll+DMA wait:%lld pht_a:%lld gain_a:%lld "
                             "store+share W1_a:%lld pht_b+corr:%lld share+G_b:%lld gain_b:%lld store_b:%lld\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[9] - h[8]);
+            std::vector<long long> wt((size_t)I * 256);
+            CSLAM_HIP_TRY(hipMemcpy(wt.data(), dStamps + 32, wt.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            const int nwg = std::min(128, round_up(n, kTile) / (32 * wide_pairs));
+            long long t0  = wt[0];
+            for (int i = 0; i < I; i++)
+            {
+                for (int b = 0; b < nwg; b++)
+                {
+                    t0 = std::min(t0, wt[(size_t)i * 256 + 2 * b]);
+                }
+            }
+            fprintf(stderr, "[cslam batch wide workgroups] instance 0, duration by block of rows (10 ns ticks):");
+            for (int b = 0; b < nwg; b++)
+            {
+                fprintf(stderr, " %lld", wt[2 * b + 1] - wt[2 * b]);
+            }
+            fprintf(stderr, "\n");
+            for (int i = 0; i < I; i++)
+            {
+                long long s0 = 1ll << 62, s1 = 0, e0 = 1ll << 62, e1 = 0, dsum = 0;
+                for (int b = 0; b < nwg; b++)
+                {
+                    const long long st = wt[(size_t)i * 256 + 2 * b] - t0, en = wt[(size_t)i * 256 + 2 * b + 1] - t0;
+                    s0 = std::min(s0, st), s1 = std::max(s1, st), e0 = std::min(e0, en), e1 = std::max(e1, en);
+                    dsum += en - st;
+                }
+                fprintf(stderr, "[cslam batch wide workgroups, 10 ns ticks] instance %d: start %lld..%lld end %lld..%lld mean duration %lld\n",
+                        i, s0, s1, e0, e1, dsum / nwg);
+            }
         }
         return CSLAM_OK;
     }

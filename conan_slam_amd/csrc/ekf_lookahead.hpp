@@ -871,7 +871,8 @@ struct LaWideArgs
     unsigned        seq;
     unsigned long long timeout;
     int*            flags;
-    long long*      stamps; // diagnostics (CSLAM_LA_STAMPS): s_memrealtime at phase boundaries of workgroup 100, or nullptr
+    long long*      stamps; // diagnostics (CSLAM_LA_STAMPS): s_memrealtime at phase boundaries of one workgroup, or nullptr
+    long long*      wg_times; // diagnostics (CSLAM_BATCH_STAMPS): {start, end} of every workgroup (s_memrealtime), or nullptr
 };
 
 __device__ __forceinline__ int la_q_of(int t, int r, int lh)
@@ -918,6 +919,10 @@ __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
         }
     };
     stamp();
+    if (a.wg_times != nullptr && tid == 0)
+    {
+        a.wg_times[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
     // ---- round 0: what does not come from the factor chain is requested before the chain is waited for: the feature ids,
     //      this row's stripe entries and state entry ...
     const int id_a = lane < a.ma ? a.idf_a[lane] : 1;
@@ -1226,6 +1231,10 @@ __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
     }
     __syncthreads(); // the row sums of the last update
     stamp();
+    if (a.wg_times != nullptr && tid == 0)
+    {
+        a.wg_times[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
     // ================= commit X and the stripe =================
     if (wv == 0 && lh == 0 && row < a.n)
     {
@@ -1487,6 +1496,7 @@ __device__ __forceinline__ LaWideArgs la_batch_wide(const LaBatchWin& w, int i)
     a.timeout    = w.timeout;
     a.flags      = w.flags + 2 * i;
     a.stamps     = i == 0 ? w.stamps : nullptr;
+    a.wg_times   = w.stamps ? w.stamps + 32 + (size_t)i * 2 * 128 : nullptr;
     return a;
 }
 
