@@ -934,7 +934,8 @@ def mc_batched(args, rank, local_rank, world, torch, dist, N, m, I, quirks):
     rec["algorithmic_bytes_per_launch"] *= per
     rec["n_sym_tiles"] *= per
     rec["roof_times_us"] = {k_: t_ * per for k_, t_ in rec["roof_times_us"].items()}
-    rec["traffic"], rec["traffic_source"] = None, None
+    rec["traffic"], tsrc = pmc_traffic(f"ekf_downdate_psym4_f32<0,4,32> batch x{per}", N, k_launch, "f32")
+    rec["traffic_source"] = (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if tsrc else None
     out = {
         "metric": "ekf_update_steps_per_sec", "value": world * I * K / elapsed, "unit": "update steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
