@@ -2318,15 +2318,13 @@ ekf_downdate_psym4_f32(float* __restrict__ P, int ldp, const float* __restrict__
                        unsigned w_span = 0, unsigned* __restrict__ signal = nullptr, unsigned sig_add = 0, int sig_count = 0,
                        int sig_stride = 0)
 {
-    // BATCH: the kernels launched before this one on the stream have finished and their results are visible device-wide
-    // (kernel boundary): tell the `sig_count` factor chains that wait for them (ekf_la_chain_batch; one counter each).
-    // One atomic per instance here replaces a release fence + atomic in every workgroup of the blocks kernel.
-    if constexpr (BATCH)
+    // Look-ahead windows: the kernels launched before this one on the stream have finished and their results are visible
+    // device-wide (kernel boundary): tell the `sig_count` factor chains that wait for them (ekf_la_chain_kernel /
+    // ekf_la_chain_batch; one counter each).  One atomic per filter here replaces a release fence + atomic in every workgroup
+    // of the blocks kernel.
+    if (signal != nullptr && blockIdx.x == 0 && (int)threadIdx.x < sig_count)
     {
-        if (signal != nullptr && blockIdx.x == 0 && (int)threadIdx.x < sig_count)
-        {
-            atomicAdd(signal + (size_t)threadIdx.x * sig_stride, sig_add);
-        }
+        atomicAdd(signal + (size_t)threadIdx.x * sig_stride, sig_add);
     }
     // seg_off != nullptr: one tile queue per XCD.  tile_list_in is then Morton-ordered and cut into eight segments
     // (seg_off[0..8]), ticket_in / ticket_reset are eight counters each, and workgroup b works on queue b & 7 -- its
