@@ -374,6 +374,10 @@ struct Ekf : EkfBase
         }
         CSLAM_HIP_TRY(hipMalloc(&dTicket, 2 * sizeof(int)));
         CSLAM_HIP_TRY(hipMemsetAsync(dTicket, 0, 2 * sizeof(int), stream));
+        if (const char* sv = getenv("CSLAM_LA_WG_SIGNAL"))
+        {
+            la_wg_signal = atoi(sv) ? 1 : 0;
+        }
         if (const char* sv = getenv("CSLAM_PSYM_NT"))
         {
             psym_nt = atoi(sv) ? 1 : 0;
@@ -1529,6 +1533,7 @@ struct Ekf : EkfBase
     // != 0: the next P-GEMM launch (ekf_downdate_psym4_f32) adds this to la_done[0] -- the chain's go-ahead, in place of a
     // release fence + atomic in every workgroup of the blocks kernel (8.8 -> 6.6 us per window); see la_launch_window
     unsigned    la_sig_add = 0;
+    int         la_wg_signal = 0; // CSLAM_LA_WG_SIGNAL=1: always the blocks kernel's own release (A/B: the first form)
 
     // Dynamic LDS of the chain kernel <T, K>: the carry step's arrays (in f64 the factor body's arrays live in the same
     // space), padded so that the workgroup's total LDS is ~99 KB: more than 96 KB keeps the persistent P-GEMM's 64 KB
@@ -1901,8 +1906,7 @@ struct Ekf : EkfBase
         // the P-GEMM that follows signals the chain when it is the plain single-stream psym4 launch (always in the steady state);
         // otherwise the blocks kernel's workgroups release their rows themselves
         const int  k8f      = round_up(kp, 8);
-        static const bool wg_signal_forced = getenv("CSLAM_LA_WG_SIGNAL") != nullptr; // (A/B: the first form)
-        const bool pg_signal = !wg_signal_forced && !safe && kp > 0 && seq.count == 0 && sizeof(T) == 4 && k8f <= 128 && lower && ldp < 32768 &&
+        const bool pg_signal = !la_wg_signal && !safe && kp > 0 && seq.count == 0 && sizeof(T) == 4 && k8f <= 128 && lower && ldp < 32768 &&
                                !limbs_take(k8f) && stream_b == stream && hd_cols[wcur] == 0;
         pa.done    = pg_signal ? (unsigned*)nullptr : la_done;
         hipLaunchKernelGGL(ekf_la_blocks_kernel<T>, dim3(n_blocks), dim3(64), 0, stream, pa);

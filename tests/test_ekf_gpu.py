@@ -900,6 +900,7 @@ SWITCHES = [
     {"CSLAM_XCD_QUEUES": "1"},
     {"CSLAM_LOOKAHEAD": "1"},             # look-ahead windows forced on (default: only large f32 filters)
     {"CSLAM_LOOKAHEAD": "1", "CSLAM_LA_FUSED": "0"},   # ... with gather + gain per update instead of the one wide launch
+    {"CSLAM_LOOKAHEAD": "1", "CSLAM_LA_WG_SIGNAL": "1"},  # ... the blocks kernel releases the chain itself (no P-GEMM go-ahead)
 ]
 
 
