@@ -46,7 +46,12 @@ __global__ void ekf_la_signal_kernel(unsigned* signal, unsigned add)
 // the wide half of a look-ahead window (ekf_lookahead.hpp: ekf_la_wide_body), one filter
 __global__ void __launch_bounds__(128) ekf_la_wide_f32(LaWideArgs a)
 {
-    ekf_la_wide_body<1>(a);
+    ekf_la_wide_body<1, 0>(a);
+}
+// ... with both updates of m = 32 observations (k = 64 known at compile time)
+__global__ void __launch_bounds__(128) ekf_la_wide_f32_k64(LaWideArgs a)
+{
+    ekf_la_wide_body<1, 64>(a);
 }
 } // namespace cslam
 
@@ -374,6 +379,10 @@ struct Ekf : EkfBase
         }
         CSLAM_HIP_TRY(hipMalloc(&dTicket, 2 * sizeof(int)));
         CSLAM_HIP_TRY(hipMemsetAsync(dTicket, 0, 2 * sizeof(int), stream));
+        if (const char* sv = getenv("CSLAM_LA_K64"))
+        {
+            la_k64 = atoi(sv) ? 1 : 0;
+        }
         if (const char* sv = getenv("CSLAM_LA_WG_SIGNAL"))
         {
             la_wg_signal = atoi(sv) ? 1 : 0;
@@ -1533,6 +1542,7 @@ struct Ekf : EkfBase
     // != 0: the next P-GEMM launch (ekf_downdate_psym4_f32) adds this to la_done[0] -- the chain's go-ahead, in place of a
     // release fence + atomic in every workgroup of the blocks kernel (8.8 -> 6.6 us per window); see la_launch_window
     unsigned    la_sig_add = 0;
+    int         la_k64 = 1;       // CSLAM_LA_K64=0: the general wide kernel for m = 32 too (A/B)
     int         la_wg_signal = 0; // CSLAM_LA_WG_SIGNAL=1: always the blocks kernel's own release (A/B: the first form)
 
     // Dynamic LDS of the chain kernel <T, K>: the carry step's arrays (in f64 the factor body's arrays live in the same
@@ -1983,7 +1993,14 @@ struct Ekf : EkfBase
                 wa.W1b     = wa.W1a + (size_t)ka * ldp;
                 wa.ldw     = ldp;
                 wa.wv_out  = dWv;
-                hipLaunchKernelGGL(ekf_la_wide_f32, dim3(round_up(n, kTile) / 32), dim3(128), 0, stream, wa);
+                if (la_k64 && ua.m == 32 && (nu == 1 || ub.m == 32))
+                {
+                    hipLaunchKernelGGL(ekf_la_wide_f32_k64, dim3(round_up(n, kTile) / 32), dim3(128), 0, stream, wa);
+                }
+                else
+                {
+                    hipLaunchKernelGGL(ekf_la_wide_f32, dim3(round_up(n, kTile) / 32), dim3(128), 0, stream, wa);
+                }
                 CSLAM_HIP_TRY(hipGetLastError());
                 last_slot = nullptr; // (PHT is not materialised on this path: nothing for debug_last_update)
                 last_k    = 0;

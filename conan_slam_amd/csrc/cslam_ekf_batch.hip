@@ -51,13 +51,19 @@ __global__ void __launch_bounds__(256) ekf_la_chain_batch(LaBatchWin w)
 __global__ void __launch_bounds__(128) ekf_la_wide_batch1(LaBatchWin w) // (A/B: CSLAM_BATCH_WIDE_PAIRS=1)
 {
     const LaWideArgs a = la_batch_wide(w, blockIdx.y);
-    ekf_la_wide_body<1>(a);
+    ekf_la_wide_body<1, 0>(a);
 }
 // (two pairs of waves per workgroup, 256 registers: 8 waves per compute unit instead of 4, see ekf_la_wide_body)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_la_wide_batch(LaBatchWin w)
 {
     const LaWideArgs a = la_batch_wide(w, blockIdx.y);
-    ekf_la_wide_body<2>(a);
+    ekf_la_wide_body<2, 0>(a);
+}
+// ... with both updates of m = 32 observations (k = 64 known at compile time)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ekf_la_wide_batch_k64(LaBatchWin w)
+{
+    const LaWideArgs a = la_batch_wide(w, blockIdx.y);
+    ekf_la_wide_body<2, 64>(a);
 }
 
 // windows without a P-GEMM (nothing pending): the chains' go-ahead as a kernel of its own
@@ -90,6 +96,7 @@ struct cslam_ekf_batch
     long long     windows = 0;
     // A/B switches (env CSLAM_BATCH_WG_SIGNAL=1, CSLAM_BATCH_WIDE_PAIRS=1): the first forms of two stages, kept measurable
     int wg_signal = 0, wide_pairs = 2;
+    int la_k64 = 1; // CSLAM_LA_K64=0: the general wide kernel for m = 32 too (A/B)
     long long* dStamps = nullptr; // CSLAM_BATCH_STAMPS=1: see LaBatchWin::stamps (printed after 300 windows)
     // bench support: HIP events around one P-GEMM launch in `prof_every` (an event pair costs ~11 us of stream time)
     int                                          prof_every = 0;
@@ -176,6 +183,10 @@ struct cslam_ekf_batch
         if (const char* e = getenv("CSLAM_BATCH_WG_SIGNAL"))
         {
             wg_signal = atoi(e) ? 1 : 0;
+        }
+        if (const char* e = getenv("CSLAM_LA_K64"))
+        {
+            la_k64 = atoi(e) ? 1 : 0;
         }
         if (const char* e = getenv("CSLAM_BATCH_WIDE_PAIRS"))
         {
@@ -378,7 +389,14 @@ struct cslam_ekf_batch
         }
         else
         {
-            hipLaunchKernelGGL(ekf_la_wide_batch, dim3(round_up(n, kTile) / 64, I), dim3(256), 0, stream, w);
+            if (la_k64 && w.ma == 32 && (w.nu == 1 || w.mb == 32))
+            {
+                hipLaunchKernelGGL(ekf_la_wide_batch_k64, dim3(round_up(n, kTile) / 64, I), dim3(256), 0, stream, w);
+            }
+            else
+            {
+                hipLaunchKernelGGL(ekf_la_wide_batch, dim3(round_up(n, kTile) / 64, I), dim3(256), 0, stream, w);
+            }
         }
         CSLAM_HIP_TRY(hipGetLastError());
         kp = ka + kb;

@@ -883,7 +883,10 @@ __device__ __forceinline__ int la_q_of(int t, int r, int lh)
 // PAIRS: pairs of waves per workgroup (1: the single filter's kernel; 2: the batched engine's -- two blocks of 32 rows share
 // ONE copy of the staged factor outputs, so that twice the waves fit a compute unit: the batch has ~1000 blocks of rows
 // where a single filter has ~300).
-template <int PAIRS = 1>
+// KFIX: 0, or the number of columns of BOTH updates' panels known at compile time (64: m = 32 observations per update, the
+// benchmark shape).  The operand reads of the three matrix products then have immediate LDS offsets and no range selects:
+// the gain and correction phases are ~600 vector instructions of address arithmetic and selects each otherwise.
+template <int PAIRS = 1, int KFIX = 0>
 __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
 {
     // TWO waves per block of 32 rows.  Wave w owns column tile w (32 columns) of every product -- half the matrix-core
@@ -910,7 +913,7 @@ __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
     const int row0 = (blockIdx.x * PAIRS + pr) * 32;
     const int row  = row0 + lj;
     const int rowc = row < a.n ? row : a.n - 1;
-    const int ka = 2 * a.ma, kb = 2 * a.mb;
+    const int ka = KFIX ? KFIX : 2 * a.ma, kb = KFIX ? KFIX : 2 * a.mb; // (KFIX: the host checked ma, and mb when nu == 2)
     int       stamp_i = 0;
     auto      stamp   = [&]() {
         if (a.stamps != nullptr && blockIdx.x == (gridDim.x >> 1) && tid == 0)
