@@ -922,9 +922,12 @@ __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
         }
     };
     stamp();
-    if (a.wg_times != nullptr && tid == 0)
+    if constexpr (PAIRS == 2) // (diagnostics of the batched engine only)
     {
-        a.wg_times[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (a.wg_times != nullptr && tid == 0)
+        {
+            a.wg_times[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
     }
     // ---- round 0: what does not come from the factor chain is requested before the chain is waited for: the feature ids,
     //      this row's stripe entries and state entry ...
@@ -1234,9 +1237,12 @@ __device__ __forceinline__ void ekf_la_wide_body(const LaWideArgs& a)
     }
     __syncthreads(); // the row sums of the last update
     stamp();
-    if (a.wg_times != nullptr && tid == 0)
+    if constexpr (PAIRS == 2)
     {
-        a.wg_times[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (a.wg_times != nullptr && tid == 0)
+        {
+            a.wg_times[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
     }
     // ================= commit X and the stripe =================
     if (wv == 0 && lh == 0 && row < a.n)
