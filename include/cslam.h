@@ -171,7 +171,9 @@ int cslam_ekf_run_many(cslam_ekf_t* handles, int count, int steps, const double*
  *   run: `steps` x { predict(v[t], swa[t], Q, wb, dt); update(Z_t, R, idf_t, batch) } on every instance; the controls are
  *        common to the instances (as in cslam_ekf_run_many), dZ[i] / d_idf[i] are instance i's device-resident inputs,
  *        steps x (2*m floats) and steps x (m ints), step-major; 9 <= m <= 32.  Asynchronous: returns when the work has
- *        been enqueued.  Feature indices are checked on the device (CSLAM_FACTOR_BAD_IDF).
+ *        been enqueued.  Feature indices are checked on the device (CSLAM_FACTOR_BAD_IDF).  Windows are formed within a
+ *        call -- steps (0,1), (2,3), ...; an odd call ends with a window of one update -- so the rounding of a run depends
+ *        on how its steps are cut into calls (as a single handle's does on when its updates arrive).
  *   flush applies the pending covariance panels; get_state / trace flush and synchronise; factor_status synchronises and
  *   writes one flag word per instance.  instances * (round_up(n, 128))^2 * 4 must stay below 4 GiB. */
 typedef struct cslam_ekf_batch* cslam_ekf_batch_t;

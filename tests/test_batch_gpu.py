@@ -81,8 +81,13 @@ def _batch(loads, quirks, ctrl, inputs, steps, calls):
     (TEXTBOOK, 2, 300, 20, 5, (5,)),       # k = 40; the last window holds one update
     (REF_EXACT, 3, 300, 32, 4, (2, 2)),    # the reference's gain, two run() calls
     (TEXTBOOK, 8, 2000, 32, 6, (4, 2)),    # BASELINE configs[4]'s per-GPU share
+    (TEXTBOOK, 2, 40, 9, 3, (2, 1)),       # one tile per filter (n = 83), the smallest batch the engine takes (m = 9)
+    (TEXTBOOK, 16, 150, 16, 2, (2,)),      # more filters than XCDs
 ])
 def test_batched_instances_equal_solo_lookahead_runs(gpu_required, monkeypatch, quirks, n_inst, N, m, steps, calls):
+    # (every run() call but the last has an even number of steps: the single handle pairs updates as they arrive, and the
+    # bitwise comparison needs both engines to form the same windows)
+    assert all(c % 2 == 0 for c in calls[:-1])
     from conan_slam_amd.synth import Workload
 
     monkeypatch.setenv("CSLAM_LOOKAHEAD", "1")
