@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -37,6 +38,14 @@ inline int fail(int code, const char* fmt, ...)
                                  __FILE__, __LINE__);                                                    \
         }                                                                                                \
     } while (0)
+
+// Engines (single-filter handles and batched handles) alive in this process: kernels that wait inside a launch are only
+// safe while ONE engine has the device to itself (see cslam_ekf.hip); every create / destroy counts here.
+inline std::atomic<int>& live_engines()
+{
+    static std::atomic<int> n{0};
+    return n;
+}
 
 inline int round_up(int v, int m)
 {

@@ -67,7 +67,7 @@ namespace
 // engine's waiting kernel in a second queue) and spinning wide kernels can hold every compute unit -- measured as 0.2 s
 // time-outs with 8 co-running instances.  So with more than one engine alive: windows only if forced
 // (CSLAM_LOOKAHEAD=1), and then with stream events only (ev_raw / ev_fb): a plain dependency graph, no waiting kernels.
-std::atomic<int> g_engines{0};
+std::atomic<int>& g_engines = ::cslam::live_engines();
 
 constexpr int    kStagingSlots = 64;
 constexpr size_t kLdsBudget    = 150 * 1024; // of the 160 KiB per CU, leave room for the small arrays

@@ -491,6 +491,7 @@ int cslam_ekf_batch_create(int instances, int n_landmarks, int device, int quirk
         delete b;
         return rc;
     }
+    live_engines().fetch_add(1); // (a single-filter handle created beside this one keeps its kernels free of waits)
     *out = b;
     return CSLAM_OK;
 }
@@ -501,6 +502,7 @@ int cslam_ekf_batch_destroy(cslam_ekf_batch_t h)
     {
         return CSLAM_OK;
     }
+    live_engines().fetch_sub(1);
     h->release();
     delete h;
     return CSLAM_OK;
