@@ -405,9 +405,10 @@ def ekf_main(args):
         step(t)
     eng.flush()  # (the timed region starts from an applied state: the warm-up's pending P-GEMM is not billed to it,
     barrier()    #  and the K timed steps pay for all of their own, the final flush included)
-    # HIP events around a sample of the P-GEMM launches of the timed region, on the stream they run on (an event pair
-    # costs ~11 us of stream time around the kernel it brackets: one launch in 16, or in 4 for short runs)
-    eng.set_profiling(3 if args.steps >= 200 else 4)
+    # HIP events around a sample of the P-GEMM launches of the timed region, on the stream they run on: one launch in 16
+    # (an event pair costs ~11 us of stream time around the kernel it brackets; a short run -- the driver's 20 steps are
+    # ten launches -- keeps one in-region sample and is priced on the bracketed pass that follows, see `bracketed_pass`)
+    eng.set_profiling(3)
     barrier()
     t0 = time.perf_counter()
     for t in range(pre_cap + args.warmup, total):
